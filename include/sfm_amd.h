@@ -1,0 +1,128 @@
+/* sfm_amd.h - C ABI of libsfm_amd.so, the MI355X (gfx950) implementation of the
+ * view-synthesis hot path of alncat/SFM.
+ *
+ * The reference has no FFI layer: its boundary for this path is the set of Python
+ * functions in utils.py, called from SfMLearner_uni.py:120-144.  Each entry point
+ * below names the reference function (file:line, relative to the reference repo) whose
+ * arithmetic it replaces; `sfm_amd/utils.py` binds them with ctypes behind the
+ * reference's own signatures (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *   - all tensors are dense, contiguous fp32 device (HBM) pointers, layout NHWC;
+ *     depth is [B,H,W]; coords are [B,H,W,2] = (x, y) in pixels; int outputs int32;
+ *   - `stream` is a hipStream_t (NULL = the default stream); every call only enqueues
+ *     work on it - no allocation, no host synchronisation, no global mutable state;
+ *   - return value: 0 on success, SFM_ERR_* (< 0) for rejected arguments, otherwise
+ *     the hipError_t (> 0) of the failed launch.  Nothing throws across the ABI;
+ *   - inputs are never written; workspaces are caller-provided and documented per call;
+ *   - `params` is the [n_src*B, SFM_PARAM_STRIDE] table written by sfm_pose_setup
+ *     (inverse intrinsics + projection matrix per source and batch item).
+ */
+#ifndef SFM_AMD_H
+#define SFM_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_PARAM_STRIDE 32
+#define SFM_ERR_ARG (-1)
+#define SFM_ERR_TOO_LARGE (-2)
+
+/* ---- per-batch set-up ------------------------------------------------------------
+ * pose_vec2mat utils.py:77-96 (euler2mat 27-75), tf.matrix_inverse(intrinsics) utils.py:112,
+ * optional tf.matrix_inverse(pose) utils.py:189/224, K4*T utils.py:195-201 == 230-236.
+ * pose element (b, i, k) is read at pose[b*pose_sb + i*pose_si + k]; item i*B+b of
+ * params receives Kinv[9], P[12]. */
+int sfm_pose_setup(const float* pose, long pose_sb, long pose_si, const float* K, int B, int n_src,
+                   int inverse_pose, float* params, void* stream);
+
+/* Adjoint of sfm_pose_setup: sums the dL/dP block partials [n_sets][n_src*B][nblk][12]
+ * written by the *_bwd calls and chains them through K4*T, the optional inverse and
+ * euler2mat (TF autodiff of the same lines; implicit in SfMLearner_uni.py:306).
+ * d_pose element (b, i, k) is written at d_pose[b*dpose_sb + i*dpose_si + k], scaled by gscale. */
+int sfm_pose_grad(const float* pose, long pose_sb, long pose_si, const float* K, const float* partials,
+                  int n_sets, int nblk, int B, int n_src, int inverse_pose, float gscale, float* d_pose,
+                  long dpose_sb, long dpose_si, void* stream);
+
+/* number of dL/dP partial blocks per batch item the *_bwd calls write for an HxW image */
+int sfm_bwd_blocks(int H, int W);
+
+/* ---- geometry only: meshgrid 146-170 -> pixel2cam 98-122 -> cam2pixel 124-144 ----
+ * coords [B,H,W,2], z [B,H,W] (may be NULL).  trans (may be NULL) = add_trans=False. */
+int sfm_project_coords(const float* depth, const float* trans, const float* params, int B, int H, int W,
+                       float* coords, float* z, void* stream);
+
+/* ---- gather direction --------------------------------------------------------------
+ * bilinear_sampler utils.py:241-340.  out [B,Ht,Wt,C], mask [B,Ht,Wt,1].
+ * idx_dump (may be NULL): int32 [B,Ht,Wt,4] = clipped (x0, x1, y0, y1) of utils.py:286-289. */
+int sfm_bilinear_sampler_fwd(const float* img, const float* coords, int B, int Hs, int Ws, int C, int Ht,
+                             int Wt, float* out, float* mask, int* idx_dump, void* stream);
+/* d_coords [B,Ht,Wt,2]; d_img (may be NULL) must be zero-filled [B,Hs,Ws,C], accumulated atomically. */
+int sfm_bilinear_sampler_bwd(const float* img, const float* coords, const float* gout, int B, int Hs, int Ws,
+                             int C, int Ht, int Wt, float* d_coords, float* d_img, void* stream);
+
+/* projective_inverse_warp utils.py:207-239 with the geometry fused (no meshgrid / cam /
+ * coords tensors are materialised). */
+int sfm_inverse_warp_fwd(const float* img, const float* depth, const float* trans, const float* params, int B,
+                         int H, int W, int C, float* out, float* mask, int* idx_dump, void* stream);
+/* d_depth [B,H,W], d_trans [B,H,W,3] (iff trans), partials [B][sfm_bwd_blocks][12]. */
+int sfm_inverse_warp_bwd(const float* img, const float* depth, const float* trans, const float* params,
+                         const float* gout, int B, int H, int W, int C, float* d_depth, float* d_trans,
+                         float* partials, float* d_img, void* stream);
+
+/* ---- splat direction ---------------------------------------------------------------
+ * bilinear_project utils.py:342-502.  z (may be NULL) = use_depth=False.
+ * acc: workspace [B,H,W,C+1] (zeroed by the call; the backward reads it again).
+ * out [B,H,W,C], mask [B,H,W,C]. */
+int sfm_bilinear_project_fwd(const float* img, const float* coords, const float* z, int B, int H, int W, int C,
+                             float* acc, float* out, float* mask, void* stream);
+int sfm_bilinear_project_bwd(const float* img, const float* coords, const float* z, const float* acc,
+                             const float* gout, int B, int H, int W, int C, float* d_coords, float* d_z,
+                             float* d_img, void* stream);
+
+/* projective_warp utils.py:172-205 with the geometry fused. */
+int sfm_splat_warp_fwd(const float* img, const float* depth, const float* trans, const float* params, int B,
+                       int H, int W, int C, float* acc, float* out, float* mask, void* stream);
+int sfm_splat_warp_bwd(const float* img, const float* depth, const float* trans, const float* params,
+                       const float* acc, const float* gout, int B, int H, int W, int C, float* d_depth,
+                       float* d_trans, float* partials, float* d_img, void* stream);
+
+/* ---- SSIM: tf_ssim utils.py:548-575 (window 504-519), 3 channels ---------------------
+ * out = the raw SSIM map `value` of line 572, [B,H,W,3]. */
+int sfm_ssim_fwd(const float* img1, const float* img2, int B, int H, int W, float* out, void* stream);
+/* gv = dL/d value; coef = workspace B*H*W*15 floats; d1 / d2 may be NULL (not both). */
+int sfm_ssim_bwd(const float* img1, const float* img2, const float* gv, int B, int H, int W, float* coef,
+                 float* d1, float* d2, void* stream);
+
+/* ---- fused multi-scale photometric loss: SfMLearner_uni.py:85-168 ----------------------
+ * S scales x N sources (2 <= N <= 4) of {projective_inverse_warp :120, projective_warp :128,
+ * L1 + SSIM :137-144, masked means :149, min-reprojection :168}, forward and backward,
+ * in a fixed number of launches.  Layouts: tgt [B,H,W,3], src [B,H,W,3N] (the reference's
+ * src_image_stack), depth [S,B,H,W] (pred_depth resized to HxW, :91), trans [S,B,H,W,3N]
+ * (pred_exp_logits resized, :109-113), pose [B,N,6], K [B,3,3], params from
+ * sfm_pose_setup(pose, 6N, 6, K, B, N, 0, ...).
+ * ws: workspace of sfm_loss_workspace_floats() floats, shared by both calls of a step.
+ *
+ * sfm_loss_forward writes partials[S*(3N+1)] (fp64): per scale, per source the sums
+ * (sum m|Sp-src|, sum m, sum ssim(Sp,src)) and then sum min(e_0,e_1).  Under data
+ * parallelism these are all-reduced (sum) across ranks before sfm_loss_backward; that is
+ * the only collective of the path.
+ * sfm_loss_backward turns the (global) sums into the loss (one float at loss_out; the
+ * pixel_loss of :149+:168) and, if need_grad, into d_depth [S,B,H,W], d_trans [S,B,H,W,3N]
+ * and d_pose [B,N,6], each scaled by gloss (dL/d loss).  n_elem_global = B_global*H*W*3. */
+long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N);
+int sfm_loss_num_partials(int B, int H, int W, int S, int N);
+int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
+                     const float* params, float* ws, int B, int H, int W, int S, int N, double* partials,
+                     void* stream);
+int sfm_loss_backward(const float* tgt, const float* src, const float* depth, const float* trans,
+                      const float* params, float* ws, int B, int H, int W, int S, int N,
+                      long long n_elem_global, float gloss, int need_grad, const double* partials,
+                      const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
+                      float* d_pose, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_AMD_H */

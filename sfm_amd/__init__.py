@@ -1,0 +1,20 @@
+"""sfm_amd - MI355X (gfx950) implementation of the view-synthesis warp + photometric
+loss hot path of alncat/SFM, behind the reference's own function signatures.
+
+    from sfm_amd.utils import projective_inverse_warp, projective_warp, \
+        bilinear_sampler, bilinear_project, tf_ssim
+    from sfm_amd.loss import multi_scale_loss
+
+The compute lives in ``libsfm_amd.so`` (hand-written HIP, C ABI in include/sfm_amd.h);
+this package only validates arguments, allocates outputs with torch and binds the
+calls.  There is no CPU or PyTorch fallback.
+"""
+from . import _lib  # noqa: F401
+from .utils import (bilinear_project, bilinear_sampler, cam2pixel, corner_indices, euler2mat, meshgrid,  # noqa: F401
+                    pixel2cam, pose_vec2mat, project_coords, projective_inverse_warp, projective_warp, ssim_value,
+                    tf_ssim)
+from .loss import compute_smooth_loss, multi_scale_loss, resize_bilinear  # noqa: F401
+
+__all__ = ["projective_inverse_warp", "projective_warp", "bilinear_sampler", "bilinear_project", "tf_ssim",
+           "ssim_value", "pose_vec2mat", "euler2mat", "meshgrid", "pixel2cam", "cam2pixel", "project_coords",
+           "corner_indices", "multi_scale_loss", "compute_smooth_loss", "resize_bilinear"]
