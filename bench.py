@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: warp + photometric loss, forward + backward, Gpix/s (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the fused hot path (sfm_loss_forward -> [all-reduce of the fp64
+partial sums when N > 1] -> sfm_loss_backward) over one batch of synthetic KITTI-shaped
+snippets that is already resident in HBM.  Workload (configs[1] of BASELINE.json):
+416x128, B=8 per GPU, seq=3 (2 sources), 4 scales.  Weak scaling: every rank holds its
+own 8 snippets; the loss is the global one.
+
+Unit of work: a pixel-warp = one target pixel through one projective warp (gather or
+splat direction) + its loss terms, forward and backward: B*H*W*S*N*2 per step and GPU.
+
+The JSON line also carries
+  roofline      the dominant kernel of the step: algorithmic bytes per launch / its mean
+                launch duration (HIP events recorded by the library on the launch stream,
+                in a second, instrumented pass of the same K steps) against 8 TB/s;
+  cpu_baseline  the CPU oracle (oracle/ref_graph.py, "port" of the reference's TF graph
+                to torch-CPU ops) timed on the host cores on the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, B, S, N = 128, 416, 8, 4, 2
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+STAGES = ["memset", "warp_fwd", "stencil_fwd", "reduce", "finalize", "stencil_bwd", "warp_bwd", "pose_grad"]
+KERNEL_OF = {"warp_fwd": "loss_warp_fwd_kernel", "stencil_fwd": "loss_stencil_fwd_kernel",
+             "stencil_bwd": "loss_stencil_bwd_kernel", "warp_bwd": "loss_warp_bwd_kernel", "memset": "hipMemsetAsync"}
+
+
+def algorithmic_bytes(n_src: int) -> dict:
+    """Distinct fp32 tensor bytes each kernel must move per (pixel, scale) - DESIGN.md section 4."""
+    n, g = n_src, min(n_src, 2)
+    return {
+        "memset": 16 * n,                                     # Acc zero-fill
+        "warp_fwd": 4 + 12 + 12 * n + 12 * g + 12 * g,        # depth, tgt, trans, src taps, G out (+64 B/source of atomics)
+        "stencil_fwd": 16 * n + 12 * n + 12 * g + 12,         # Acc, src, G, tgt
+        "stencil_bwd": 16 * n + 12 * n + 12 * g + 12 + 16 * n + 12 * g,   # + Hb out, dG out
+        "warp_bwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 16 * n + 4 + 12 * n,  # + dG, Hb in; d_depth, d_trans out
+    }
+
+
+def cpu_baseline(seed: int) -> dict:
+    from oracle import ref_graph as R
+    from sfm_amd import synth
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=seed)
+
+    def step():
+        depth = [d.clone().requires_grad_(True) for d in inp["depth"]]
+        trans = [t.clone().requires_grad_(True) for t in inp["trans"]]
+        pose = inp["pose"].clone().requires_grad_(True)
+        loss = R.multi_scale_loss(inp["tgt"], inp["src"], inp["K"], depth, pose, trans)
+        loss.backward()
+        return float(loss)
+
+    step()
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all) < 25.0:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    units = B * H * W * S * N * 2
+    return {"value": units / med / 1e9, "unit": "Gpix/s", "cores": cores, "kind": "port",
+            "sample": f"full workload (B={B} {W}x{H} S={S} N={N}), fwd+bwd via torch autograd, median of {len(times)} "
+                      f"steps after 1 warm-up ({med * 1e3:.0f} ms/step), reference-equivalent CPU graph "
+                      f"(PyTorch-CPU restatement; TensorFlow is not installable here)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from sfm_amd import _lib, synth
+    from sfm_amd.loss import LossEngine
+    lib = _lib.load()
+
+    inp = synth.to_device(synth.make_inputs(B, H, W, S=S, N=N, seed=synth.SEED + rank), dev)
+    tgt, src, K, pose = inp["tgt"], inp["src"], inp["K"], inp["pose"]
+    depth = torch.stack([d.squeeze(3) for d in inp["depth"]], 0).contiguous()
+    trans = torch.stack(inp["trans"], 0).contiguous()
+    eng = LossEngine(B, H, W, S, N, dev)
+    n_elem_global = world * B * H * W * 3
+
+    def step():
+        partials = eng.forward_partials(tgt, src, K, depth, pose, trans)
+        if world > 1:
+            dist.all_reduce(partials)
+        return eng.backward(tgt, src, K, depth, pose, trans, partials, n_elem_global, 1.0, True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out[0])
+
+    # second, instrumented pass: HIP events around every launch, on the launch stream
+    stage_ms = (ctypes.c_float * len(STAGES))()
+    lib.sfm_prof_enable(1)
+    for _ in range(args.steps):
+        step()
+        torch.cuda.synchronize()
+        lib.sfm_prof_read(stage_ms)
+    lib.sfm_prof_enable(0)
+
+    if rank == 0:
+        units_per_gpu = B * H * W * S * N * 2
+        ms_step = dt / args.steps * 1e3
+        value = units_per_gpu * world / (dt / args.steps) / 1e9
+        per_stage_us = {n: stage_ms[i] / args.steps * 1e3 for i, n in enumerate(STAGES)}
+        ab = algorithmic_bytes(N)
+        dom = max(ab, key=lambda n: per_stage_us[n])
+        launch_bytes = ab[dom] * B * H * W * S
+        achieved = launch_bytes / (per_stage_us[dom] * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(KERNEL_OF.get(dom, dom))
+        step_bytes = (108 + 152) * B * H * W * S * N  # gather 108 B + splat 152 B per pair
+        line = {
+            "metric": "warp+loss fwd+bwd Gpix/s at 416x128 B=8 (1/2/4/8 GPU), % HBM roofline",
+            "value": value, "unit": "Gpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} B={B}/GPU seq=3 (N={N} sources) S={S} scales, warp+photometric loss "
+                                   f"fwd+bwd (BASELINE.json configs[1])",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "pixel_warps_per_step": units_per_gpu * world,
+                       "loss": loss},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": per_stage_us[dom],
+                         "stage_us": per_stage_us,
+                         "step_frac_of_hbm_peak": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(synth.SEED)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

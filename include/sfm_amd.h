@@ -122,6 +122,15 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
                       const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
                       float* d_pose, void* stream);
 
+/* ---- measurement aid (no counterpart in the reference; used by bench.py only) -----------
+ * When enabled, sfm_loss_forward / sfm_loss_backward bracket each of their launches with
+ * HIP events on the caller's stream; sfm_prof_read adds the last step's elapsed ms per stage
+ * into ms[sfm_prof_stages()] (order: memset, warp_fwd, stencil_fwd, reduce, finalize,
+ * stencil_bwd, warp_bwd, pose_grad) after the caller synchronised.  Process-wide, off by default. */
+int sfm_prof_enable(int on);
+int sfm_prof_stages(void);
+int sfm_prof_read(float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -579,6 +579,29 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
   }
 }
 
+
+// ------------------------------------------------------------------ per-stage timing
+// Optional measurement aid for bench.py: when enabled, the two loss entry points bracket
+// each launch with HIP events on the caller's stream.  Off by default (no events, no
+// overhead); process-wide, not thread-safe - a bench facility, not part of the data path.
+enum { ST_MEMSET = 0, ST_WARP_FWD, ST_STENCIL_FWD, ST_REDUCE, ST_FINALIZE, ST_STENCIL_BWD, ST_WARP_BWD, ST_POSE_GRAD,
+       ST_COUNT };
+static bool g_prof_on = false;
+static hipEvent_t g_ev[ST_COUNT][2];
+static bool g_ev_used[ST_COUNT];
+static bool g_ev_made = false;
+
+struct StageTimer {
+  int id;
+  hipStream_t st;
+  StageTimer(int id_, hipStream_t st_) : id(id_), st(st_) {
+    if (g_prof_on) { (void)hipEventRecord(g_ev[id][0], st); }
+  }
+  ~StageTimer() {
+    if (g_prof_on) { (void)hipEventRecord(g_ev[id][1], st); g_ev_used[id] = true; }
+  }
+};
+
 static inline bool dims_ok(const LossDims& d) {
   return d.B > 0 && d.H > 0 && d.W > 0 && d.S > 0 && d.N >= 2 && d.N <= kMaxSrc && d.B <= 65535 && d.S <= 65535 &&
          (long)d.S * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 4 ? 3 * d.N : 4);
@@ -613,14 +636,20 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_ws(d);
   const size_t npx = (size_t)B * H * W;
-  hipError_t e = hipMemsetAsync(ws + w.Acc, 0, (size_t)S * N * npx * 4 * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  {
+    StageTimer t(ST_MEMSET, stream);
+    hipError_t e = hipMemsetAsync(ws + w.Acc, 0, (size_t)S * N * npx * 4 * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  { StageTimer t(ST_WARP_FWD, stream);
   hipLaunchKernelGGL(loss_warp_fwd_kernel, dim3(w.nblk_bwd, B, S), dim3(kBlock), 0, stream, tgt, src, depth, trans,
-                     params, d, sfm_lin_step(W), sfm_lin_step(H), ws + w.G, ws + w.Acc);
+                     params, d, sfm_lin_step(W), sfm_lin_step(H), ws + w.G, ws + w.Acc); }
+  { StageTimer t(ST_STENCIL_FWD, stream);
   hipLaunchKernelGGL(loss_stencil_fwd_kernel, dim3(w.tiles_x, w.tiles_y, S * B), dim3(kBlock), 0, stream, tgt, src,
-                     ws + w.G, ws + w.Acc, d, ws + w.blkp);
+                     ws + w.G, ws + w.Acc, d, ws + w.blkp); }
+  { StageTimer t(ST_REDUCE, stream);
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(S), dim3(kBlock), 0, stream, ws + w.blkp, B * w.tiles_x * w.tiles_y, N,
-                     partials);
+                     partials); }
   return sfm_last_error();
 }
 
@@ -637,17 +666,54 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
     return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_ws(d);
+  { StageTimer t(ST_FINALIZE, stream);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, gloss,
-                     ws + w.coef, loss_out);
+                     ws + w.coef, loss_out); }
   if (!need_grad) return sfm_last_error();
   if (!pose || !K || !d_depth || !d_trans || !d_pose) return SFM_ERR_ARG;
+  { StageTimer t(ST_STENCIL_BWD, stream);
   hipLaunchKernelGGL(loss_stencil_bwd_kernel, dim3(w.tiles_x, w.tiles_y, S * B), dim3(kBlock), 0, stream, tgt, src,
-                     ws + w.G, ws + w.Acc, ws + w.coef, d, ws + w.Hb, ws + w.dG);
+                     ws + w.G, ws + w.Acc, ws + w.coef, d, ws + w.Hb, ws + w.dG); }
+  { StageTimer t(ST_WARP_BWD, stream);
   hipLaunchKernelGGL(loss_warp_bwd_kernel, dim3(w.nblk_bwd, B, S), dim3(kBlock), 0, stream, tgt, src, depth, trans,
                      params, ws + w.Hb, ws + w.dG, d, sfm_lin_step(W), sfm_lin_step(H), d_depth, d_trans,
-                     ws + w.dPp);
+                     ws + w.dPp); }
   int rc = sfm_last_error();
   if (rc) return rc;
   // pose [B,N,6]: element (b,i,k) at b*6N + i*6 + k; partial sets = scales
+  StageTimer t(ST_POSE_GRAD, stream);
   return sfm_pose_grad(pose, 6L * N, 6L, K, ws + w.dPp, S, w.nblk_bwd, B, N, 0, 1.0f, d_pose, 6L * N, 6L, stream_);
+}
+
+// ---- measurement aid (bench.py): per-launch HIP-event timing of the two calls above ----
+extern "C" int sfm_prof_enable(int on) {
+  if (on && !g_ev_made) {
+    for (int i = 0; i < ST_COUNT; ++i)
+      for (int k = 0; k < 2; ++k) {
+        hipError_t e = hipEventCreate(&g_ev[i][k]);
+        if (e != hipSuccess) return (int)e;
+      }
+    g_ev_made = true;
+  }
+  for (int i = 0; i < ST_COUNT; ++i) g_ev_used[i] = false;
+  g_prof_on = on != 0;
+  return SFM_OK;
+}
+
+extern "C" int sfm_prof_stages(void) { return ST_COUNT; }
+
+// Adds the elapsed milliseconds of the last step's launches into ms[ST_COUNT]; the
+// caller must have synchronised the stream.  Stage order: memset, warp_fwd, stencil_fwd,
+// reduce, finalize, stencil_bwd, warp_bwd, pose_grad.
+extern "C" int sfm_prof_read(float* ms) {
+  if (!g_ev_made || !ms) return SFM_ERR_ARG;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    if (!g_ev_used[i]) continue;
+    float t = 0.f;
+    hipError_t e = hipEventElapsedTime(&t, g_ev[i][0], g_ev[i][1]);
+    if (e != hipSuccess) return (int)e;
+    ms[i] += t;
+    g_ev_used[i] = false;
+  }
+  return SFM_OK;
 }

@@ -32,7 +32,7 @@ def test_arity_matches_header():
     text = open(os.path.join(ROOT, "include", "sfm_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     for name, args in re.findall(r"\b(sfm_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
-        assert len([a for a in args.split(",") if a.strip()]) == len(_lib.SIGNATURES[name]), name
+        assert len([a for a in args.split(",") if a.strip() and a.strip() != "void"]) == len(_lib.SIGNATURES[name]), name
 
 
 def test_pure_host_entry_points():
