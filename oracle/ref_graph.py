@@ -491,3 +491,47 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
     if return_parts:
         return total, pixel_loss, smooth_loss, parts
     return total
+
+
+# ----------------------------------------------------------------------------
+# data-parallel decomposition of the pixel loss
+# ----------------------------------------------------------------------------
+def loss_partials(tgt_image, src_image_stack, intrinsics, pred_depth, pred_poses, pred_exp_logits,
+                  alpha: float = 0.15) -> Tensor:
+    """The S*(3N+1) fp64 sums one data-parallel rank contributes: per scale and source
+    (sum m|Sp-src|, sum m, sum ssim(Sp,src)) and per scale sum min(e_0,e_1).  These are
+    exactly the quantities behind every ``reduce_mean`` of SfMLearner_uni.py:149,168 and
+    utils.py:574; summed over ranks they give the single-device loss (tested with gloo)."""
+    bsz, height, width, _ = tgt_image.shape
+    num_source = pred_poses.shape[1]
+    out = []
+    for s in range(len(pred_depth)):
+        depth_s = resize_bilinear_tf1(pred_depth[s], height, width)
+        errs = []
+        for i in range(num_source):
+            trans = resize_bilinear_tf1(pred_exp_logits[s][..., 3 * i:3 * i + 3], height, width)
+            src_i = src_image_stack[..., 3 * i:3 * i + 3]
+            proj_image, _ = projective_inverse_warp(src_i, depth_s.squeeze(3), pred_poses[:, i, :], intrinsics,
+                                                    add_trans=True, translations=trans)
+            sp, m = projective_warp(tgt_image, depth_s.squeeze(3), pred_poses[:, i, :], intrinsics, add_trans=True,
+                                    translations=trans)
+            errs.append(alpha * (proj_image - tgt_image).abs()
+                        + (1 - alpha) * tf_ssim(proj_image, tgt_image, size=3, mean_metric=False))
+            out += [(m * (sp - src_i).abs()).double().sum(), m.double().sum(), ssim_value(sp, src_i).double().sum()]
+        out.append(tf_minimum(errs[0], errs[1]).double().sum())
+    return torch.stack(out)
+
+
+def loss_from_partials(partials: Tensor, num_scales: int, num_source: int, n_elem_global: int,
+                       alpha: float = 0.15) -> Tensor:
+    """pixel_loss of SfMLearner_uni.py:149,168 from the (globally summed) partials."""
+    p = partials.reshape(num_scales, 3 * num_source + 1).double()
+    n = float(n_elem_global)
+    loss = torch.zeros((), dtype=torch.float64)
+    for s in range(num_scales):
+        for i in range(num_source):
+            a_sum, m_sum, v_sum = p[s, 3 * i], p[s, 3 * i + 1], p[s, 3 * i + 2]
+            sc = torch.clamp((1 - (v_sum / n).float()) / 2.0, 0, 1).double()  # utils.py:573-575 on the global mean
+            loss = loss + alpha * a_sum / n + (1 - alpha) * sc * m_sum / n
+        loss = loss + 2.0 * p[s, 3 * num_source] / n
+    return loss

@@ -1,0 +1,85 @@
+"""BASELINE.json's full sizes, where the CPU oracle would take minutes: size-independent
+properties of the HIP path instead (the oracle comparisons at small sizes are in
+test_gpu_warp.py / test_gpu_loss.py / test_gpu_golden.py).
+
+  * two independent HIP implementations agree: the fused pipeline (csrc/loss.hip) and the
+    reference's op-by-op decomposition (stand-alone operators of csrc/warp.hip + ssim.hip glued
+    by torch autograd) give the same loss and gradients;
+  * the data-parallel sums are additive over the batch: partials(B) == partials(B/2) + partials(B/2)
+    - the "checksum of checksums" behind the sharding of SURVEY.md section 8e;
+  * both warps are linear in the image; a constant image splats to itself wherever anything lands.
+"""
+import pytest
+import torch
+
+import sfm_amd
+from sfm_amd import synth
+from sfm_amd.loss import LossEngine
+from helpers import TOL_GRAD, TOL_OUT, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [  # (label, B, H, W, S, N, cityscapes)
+    ("c2 416x128 B=8 S=4 seq=3", 8, 128, 416, 4, 2, False),
+    ("c3 1248x384 per-GPU slice B=4 S=4 seq=3", 4, 384, 1248, 4, 2, False),
+    ("c4 2048x1024 seq=5, B=2 S=2", 2, 1024, 2048, 2, 4, True),
+]
+
+
+def _run(inp, dev, fused):
+    g = synth.to_device(inp, dev)
+    depth = [d.requires_grad_(True) for d in g["depth"]]
+    trans = [t.requires_grad_(True) for t in g["trans"]]
+    pose = g["pose"].requires_grad_(True)
+    loss = sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], depth, pose, trans, fused=fused)
+    loss.backward()
+    return loss, depth, pose, trans
+
+
+@pytest.mark.parametrize("label,B,H,W,S,N,city", SIZES, ids=[s[0] for s in SIZES])
+def test_fused_equals_unfused_at_full_size(dev, label, B, H, W, S, N, city):
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=41, cityscapes=city)
+    lf, df, pf, tf_ = _run(inp, dev, True)
+    lu, du, pu, tu = _run(inp, dev, False)
+    assert rel_err(lf, lu) <= TOL_OUT
+    assert rel_err(pf.grad, pu.grad) <= TOL_GRAD
+    for s in range(S):
+        assert rel_err(df[s].grad, du[s].grad) <= TOL_GRAD, f"d_depth scale {s}"
+        assert rel_err(tf_[s].grad, tu[s].grad) <= TOL_GRAD, f"d_trans scale {s}"
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("label,B,H,W,S,N,city", SIZES[:2], ids=[s[0] for s in SIZES[:2]])
+def test_partials_are_additive_over_the_batch(dev, label, B, H, W, S, N, city):
+    inp = synth.to_device(synth.make_inputs(B, H, W, S=S, N=N, seed=42, cityscapes=city), dev)
+    depth = torch.stack([d.squeeze(3) for d in inp["depth"]], 0).contiguous()
+    trans = torch.stack(inp["trans"], 0).contiguous()
+
+    def part(lo, hi):
+        eng = LossEngine(hi - lo, H, W, S, N, dev)
+        return eng.forward_partials(inp["tgt"][lo:hi].contiguous(), inp["src"][lo:hi].contiguous(),
+                                    inp["K"][lo:hi].contiguous(), depth[:, lo:hi].contiguous(),
+                                    inp["pose"][lo:hi].contiguous(), trans[:, lo:hi].contiguous()).clone()
+
+    whole = part(0, B)
+    halves = part(0, B // 2) + part(B // 2, B)
+    assert rel_err(halves, whole) <= 1e-6
+
+
+def test_warps_are_linear_in_the_image_at_c4_size(dev):
+    B, H, W = 1, 1024, 2048
+    inp = synth.to_device(synth.make_inputs(B, H, W, S=1, N=2, seed=43, cityscapes=True, pose_scale=0.02), dev)
+    depth, pose, K = inp["depth"][0].squeeze(3).contiguous(), inp["pose"][:, 0].contiguous(), inp["K"]
+    t = inp["trans"][0][..., :3].contiguous()
+    a, b = inp["tgt"], inp["src"][..., :3].contiguous()
+    for fn in (sfm_amd.projective_inverse_warp, sfm_amd.projective_warp):
+        oa, _ = fn(a, depth, pose, K, add_trans=True, translations=t)
+        ob, _ = fn(b, depth, pose, K, add_trans=True, translations=t)
+        oc, _ = fn(0.25 * a - 1.5 * b, depth, pose, K, add_trans=True, translations=t)
+        assert rel_err(oc, 0.25 * oa - 1.5 * ob) <= 1e-5
+    const = torch.full_like(a, -0.62)
+    out, mask = sfm_amd.projective_warp(const, depth, pose, K, add_trans=True, translations=t)
+    hit = out != 0
+    assert float(hit.float().mean()) > 0.9
+    assert float((out[hit] + 0.62).abs().max()) < 1e-5
+    assert float(mask.min()) >= 0.0 and float(mask.max()) <= 1.0
