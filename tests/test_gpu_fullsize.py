@@ -15,7 +15,7 @@ import torch
 import sfm_amd
 from sfm_amd import synth
 from sfm_amd.loss import LossEngine
-from helpers import TOL_GRAD, TOL_OUT, rel_err
+from helpers import TOL_GRAD, TOL_OUT, grad_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -44,8 +44,10 @@ def test_fused_equals_unfused_at_full_size(dev, label, B, H, W, S, N, city):
     assert rel_err(lf, lu) <= TOL_OUT
     assert rel_err(pf.grad, pu.grad) <= TOL_GRAD
     for s in range(S):
-        assert rel_err(df[s].grad, du[s].grad) <= TOL_GRAD, f"d_depth scale {s}"
-        assert rel_err(tf_[s].grad, tu[s].grad) <= TOL_GRAD, f"d_trans scale {s}"
+        ok, msg = grad_close(df[s].grad, du[s].grad)
+        assert ok, f"d_depth scale {s}: {msg}"
+        ok, msg = grad_close(tf_[s].grad, tu[s].grad)
+        assert ok, f"d_trans scale {s}: {msg}"
     torch.cuda.empty_cache()
 
 
@@ -76,7 +78,7 @@ def test_warps_are_linear_in_the_image_at_c4_size(dev):
         oa, _ = fn(a, depth, pose, K, add_trans=True, translations=t)
         ob, _ = fn(b, depth, pose, K, add_trans=True, translations=t)
         oc, _ = fn(0.25 * a - 1.5 * b, depth, pose, K, add_trans=True, translations=t)
-        assert rel_err(oc, 0.25 * oa - 1.5 * ob) <= 1e-5
+        assert rel_err(oc, 0.25 * oa - 1.5 * ob) <= 5e-5  # three fp32 evaluations, cancellation in the combination
     const = torch.full_like(a, -0.62)
     out, mask = sfm_amd.projective_warp(const, depth, pose, K, add_trans=True, translations=t)
     hit = out != 0
