@@ -35,17 +35,16 @@ sys.path.insert(0, ROOT)
 
 H, W, B, S, N = 128, 416, 8, 4, 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-STAGES = ["memset", "warp_fwd", "stencil_fwd", "reduce", "finalize", "stencil_bwd", "warp_bwd", "pose_grad"]
-KERNEL_OF = {"warp_fwd": "loss_warp_fwd_kernel", "stencil_fwd": "loss_stencil_fwd_kernel",
-             "stencil_bwd": "loss_stencil_bwd_kernel", "warp_bwd": "loss_warp_bwd_kernel", "memset": "hipMemsetAsync"}
+STAGES = ["tile_shift", "warp_fwd", "stencil_fwd", "reduce", "finalize", "stencil_bwd", "warp_bwd", "pose_grad"]
+KERNEL_OF = {"warp_fwd": "loss_splat_tile_kernel", "stencil_fwd": "loss_stencil_fwd_kernel",
+             "stencil_bwd": "loss_stencil_bwd_kernel", "warp_bwd": "loss_warp_bwd_kernel"}
 
 
 def algorithmic_bytes(n_src: int) -> dict:
     """Distinct fp32 tensor bytes each kernel must move per (pixel, scale) - DESIGN.md section 4."""
     n, g = n_src, min(n_src, 2)
     return {
-        "memset": 16 * n,                                     # Acc zero-fill
-        "warp_fwd": 4 + 12 + 12 * n + 12 * g + 12 * g,        # depth, tgt, trans, src taps, G out (+64 B/source of atomics)
+        "warp_fwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 16 * n,   # depth, tgt, trans, src taps; G out, Acc out
         "stencil_fwd": 16 * n + 12 * n + 12 * g + 12,         # Acc, src, G, tgt
         "stencil_bwd": 16 * n + 12 * n + 12 * g + 12 + 16 * n + 12 * g,   # + Hb out, dG out
         "warp_bwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 16 * n + 4 + 12 * n,  # + dG, Hb in; d_depth, d_trans out

@@ -11,7 +11,8 @@
  *   - all tensors are dense, contiguous fp32 device (HBM) pointers, layout NHWC;
  *     depth is [B,H,W]; coords are [B,H,W,2] = (x, y) in pixels; int outputs int32;
  *   - `stream` is a hipStream_t (NULL = the default stream); every call only enqueues
- *     work on it - no allocation, no host synchronisation, no global mutable state;
+ *     work on it - no allocation, no host synchronisation, no global mutable state
+ *     (state that outlives a call lives in the caller's workspace and is documented there);
  *   - return value: 0 on success, SFM_ERR_* (< 0) for rejected arguments, otherwise
  *     the hipError_t (> 0) of the failed launch.  Nothing throws across the ABI;
  *   - inputs are never written; workspaces are caller-provided and documented per call;
@@ -102,7 +103,11 @@ int sfm_ssim_bwd(const float* img1, const float* img2, const float* gv, int B, i
  * src_image_stack), depth [S,B,H,W] (pred_depth resized to HxW, :91), trans [S,B,H,W,3N]
  * (pred_exp_logits resized, :109-113), pose [B,N,6], K [B,3,3], params from
  * sfm_pose_setup(pose, 6N, 6, K, B, N, 0, ...).
- * ws: workspace of sfm_loss_workspace_floats() floats, shared by both calls of a step.
+ * ws: workspace of sfm_loss_workspace_floats() floats, shared by both calls of a step and
+ * initialised ONCE by sfm_loss_workspace_init (it zeroes the splat's overflow accumulator and
+ * flags; every forward/backward pair leaves them zero again, so later steps pay no memset).
+ * Each sfm_loss_forward must be followed by sfm_loss_backward on the same ws (need_grad 0 or 1)
+ * before the next sfm_loss_forward; calls sharing a ws must be stream-ordered.
  *
  * sfm_loss_forward writes partials[S*(3N+1)] (fp64): per scale, per source the sums
  * (sum m|Sp-src|, sum m, sum ssim(Sp,src)) and then sum min(e_0,e_1).  Under data
@@ -113,6 +118,7 @@ int sfm_ssim_bwd(const float* img1, const float* img2, const float* gv, int B, i
  * and d_pose [B,N,6], each scaled by gloss (dL/d loss).  n_elem_global = B_global*H*W*3. */
 long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N);
 int sfm_loss_num_partials(int B, int H, int W, int S, int N);
+int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, int N, void* stream);
 int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
                      const float* params, float* ws, int B, int H, int W, int S, int N, double* partials,
                      void* stream);
@@ -125,7 +131,7 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
 /* ---- measurement aid (no counterpart in the reference; used by bench.py only) -----------
  * When enabled, sfm_loss_forward / sfm_loss_backward bracket each of their launches with
  * HIP events on the caller's stream; sfm_prof_read adds the last step's elapsed ms per stage
- * into ms[sfm_prof_stages()] (order: memset, warp_fwd, stencil_fwd, reduce, finalize,
+ * into ms[sfm_prof_stages()] (order: tile_shift, warp_fwd, stencil_fwd, reduce, finalize,
  * stencil_bwd, warp_bwd, pose_grad) after the caller synchronised.  Process-wide, off by default. */
 int sfm_prof_enable(int on);
 int sfm_prof_stages(void);

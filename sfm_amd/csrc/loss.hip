@@ -26,6 +26,7 @@
 //   dG  [S,2,B,H,W,3]     backward: dL/dG_i
 #include "sfm_device.h"
 #include "sfm_internal.h"
+#include <cstdlib>
 
 namespace sfm {
 
@@ -33,6 +34,8 @@ constexpr int kMaxSrc = 4;
 constexpr int kTerms = 3 * kMaxSrc + 1;  // block partial slots: (A,M,V) per source, then E
 constexpr int TW = 32, TH = 16;          // stencil tile (pixels) per 256-thread block
 constexpr int kLossPPT = 4;              // pixels per thread in the streaming warp kernels
+constexpr int STW = 64, STH = 16;        // splat: destination tile of one workgroup (LDS: 4 fp64 planes x 8 KiB)
+constexpr int SR = 8;                    // splat: reach of the scan window around the shifted tile
 constexpr float kAlpha = 0.15f;          // SfMLearner_uni.py:84
 
 struct LossDims {
@@ -41,8 +44,8 @@ struct LossDims {
 
 // ------------------------------------------------------------------ workspace map
 struct LossWs {
-  size_t G, Acc, Hb, dG, blkp, dPp, coef, total;
-  int tiles_x, tiles_y, nblk_bwd;
+  size_t G, Acc, Ovf, Hb, dG, blkp, dPp, coef, shift, flags, total;
+  int tiles_x, tiles_y, nblk_bwd, stiles_x, stiles_y, n_img;
 };
 
 static inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
@@ -54,72 +57,212 @@ static LossWs loss_ws(const LossDims& d) {
   w.tiles_x = (d.W + TW - 1) / TW;
   w.tiles_y = (d.H + TH - 1) / TH;
   w.nblk_bwd = (d.H * d.W + kBlock * kLossPPT - 1) / (kBlock * kLossPPT);
+  w.stiles_x = (d.W + STW - 1) / STW;
+  w.stiles_y = (d.H + STH - 1) / STH;
+  w.n_img = d.S * d.N * d.B;
   size_t o = 0;
   w.Acc = o; o += (size_t)d.S * d.N * npx * 4;
+  w.Ovf = o; o += (size_t)d.S * d.N * npx * 4;
   w.Hb = o;  o += (size_t)d.S * d.N * npx * 4;
   w.G = o;   o += up4((size_t)d.S * ng * npx * 3);
   w.dG = o;  o += up4((size_t)d.S * ng * npx * 3);
   w.blkp = o; o += up4((size_t)d.S * d.B * w.tiles_x * w.tiles_y * kTerms);
   w.dPp = o; o += up4((size_t)d.S * d.N * d.B * w.nblk_bwd * 12);
   w.coef = o; o += 64;
+  w.shift = o; o += up4((size_t)w.n_img * w.stiles_x * w.stiles_y * 2);
+  w.flags = o; o += up4((size_t)w.n_img);
   w.total = o;
   return w;
 }
 
 // ------------------------------------------------------------------ fused warp forward
-// grid (blocks, B, S).  One geometry evaluation per (pixel, source) feeds the 4-tap
-// gather (written to G) and the 4-corner Gaussian splat (atomics into Acc).
-__global__ __launch_bounds__(kBlock) void loss_warp_fwd_kernel(const float* __restrict__ tgt,
-                                                               const float* __restrict__ src,
-                                                               const float* __restrict__ depth,
-                                                               const float* __restrict__ trans,
-                                                               const float* __restrict__ params, LossDims d,
-                                                               float step_x, float step_y, float* __restrict__ G,
-                                                               float* __restrict__ Acc) {
-  const int b = blockIdx.y, s = blockIdx.z;
-  const int HW = d.H * d.W;
-  const int C3 = 3 * d.N;
+// The forward splat (utils.py:419-470) without global atomics in the common case.
+//
+// A workgroup OWNS a destination tile of STW x STH pixels of one (scale, source, batch item)
+// image and keeps its (sum g*rgb, sum g) accumulators in LDS.  It scans the window of target
+// pixels that can land in the tile - the tile moved back by the tile's estimated displacement
+// (`shift`, one int2 per tile, written by loss_tile_shift_kernel) and grown by SR pixels -
+// evaluates the geometry of each scanned pixel and adds the corners that fall inside its own
+// tile with LDS atomics (ds_add_f32).  The tile is then written to Acc with plain 16-byte
+// stores: no memset of Acc, no global atomics, every Acc element written exactly once.
+//
+// Exactness does not depend on the shift table or on SR.  Each target pixel also has a HOME
+// workgroup (the one whose tile contains the pixel itself).  For each of the pixel's four
+// corners the home workgroup evaluates the same window predicate the owner of the corner's
+// tile uses; a corner whose owner does not scan the pixel ("overflow", rare for smooth
+// warps) is added by the home workgroup to the zero-initialised side accumulator Ovf with
+// global atomics and the image's flag is raised; consumers read Acc + Ovf for flagged
+// images.  Every (pixel, corner) contribution is therefore counted exactly once.
+// The home workgroup also performs the 4-tap gather of the pixel (utils.py:297-335) -> G.
+__device__ __forceinline__ bool in_scan_window(int u, int v, int tx, int ty, int2 sft) {
+  const int xl = tx * STW - sft.x - SR, yl = ty * STH - sft.y - SR;
+  return u >= xl && u < xl + STW + 2 * SR && v >= yl && v < yl + STH + 2 * SR;
+}
+
+// One thread per (image, tile): mid-range of the displacement (x - u, y - v) over a 3x3 grid of
+// sample pixels of the tile.  Any table is correct; a good one keeps the overflow rare.
+__global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __restrict__ depth,
+                                                                 const float* __restrict__ trans,
+                                                                 const float* __restrict__ params, LossDims d,
+                                                                 float step_x, float step_y, int tiles_x, int tiles_y,
+                                                                 int2* __restrict__ shift) {
+  const int ntile = tiles_x * tiles_y;
+  const long total = (long)d.S * d.N * d.B * ntile;
+  const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= total) return;
+  const int tile = (int)(k % ntile);
+  const int img = (int)(k / ntile);  // (s*N + i)*B + b
+  const int b = img % d.B, si = img / d.B, i = si % d.N, s = si / d.N;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int HW = d.H * d.W, C3 = 3 * d.N;
+  const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
+  const size_t sb = ((size_t)s * d.B + b) * HW;
+  const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
+  const int xa = tx * STW, ya = ty * STH;
+  const int xb = min(xa + STW, d.W) - 1, yb = min(ya + STH, d.H) - 1;
+  float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f;
+  for (int jy = 0; jy < 3; ++jy)
+    for (int jx = 0; jx < 3; ++jx) {
+      const int u = xa + ((xb - xa) * jx) / 2, v = ya + ((yb - ya) * jy) / 2;
+      const int p = v * d.W + u;
+      const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
+      const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), depth[sb + p], true, t.x,
+                              t.y, t.z);
+      // displacement of the clipped landing point (what the corners are clipped to)
+      const float ddx = fminf(fmaxf(g.x, 0.0f), xmax) - (float)u, ddy = fminf(fmaxf(g.y, 0.0f), ymax) - (float)v;
+      lo_x = fminf(lo_x, ddx); hi_x = fmaxf(hi_x, ddx);
+      lo_y = fminf(lo_y, ddy); hi_y = fmaxf(hi_y, ddy);
+    }
+  const float mx = 0.5f * (lo_x + hi_x), my = 0.5f * (lo_y + hi_y);
+  int2 o;
+  o.x = (mx == mx) ? (int)rintf(fminf(fmaxf(mx, -32768.0f), 32767.0f)) : 0;
+  o.y = (my == my) ? (int)rintf(fminf(fmaxf(my, -32768.0f), 32767.0f)) : 0;
+  shift[k] = o;
+}
+
+// grid (tiles_x, tiles_y, S*N*B), 256 threads.
+__global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __restrict__ tgt,
+                                                                 const float* __restrict__ src,
+                                                                 const float* __restrict__ depth,
+                                                                 const float* __restrict__ trans,
+                                                                 const float* __restrict__ params, LossDims d,
+                                                                 float step_x, float step_y,
+                                                                 const int2* __restrict__ shift, float* __restrict__ G,
+                                                                 float* __restrict__ Acc, float* __restrict__ Ovf,
+                                                                 int* __restrict__ flags, int dbg) {
+  constexpr int TP = STW * STH;
+  // planes: sum g*r, sum g*g, sum g*b, sum g.  fp64 on purpose: on gfx950 ds_add_f64 retires a wave
+  // instruction in ~9 cycles while ds_add_f32 takes ~190 (profiles/r01_lds_atomic_microbench.txt);
+  // the float -> double conversion is exact and the sums lose nothing before the final rounding.
+  __shared__ double acc[4 * TP];
+  const int tx = blockIdx.x, ty = blockIdx.y, tiles_x = gridDim.x;
+  const int img = blockIdx.z;  // (s*N + i)*B + b
+  const int b = img % d.B, si = img / d.B, i = si % d.N, s = si / d.N;
+  const int HW = d.H * d.W, C3 = 3 * d.N;
   const int ng = d.N < 2 ? d.N : 2;
-  const size_t img = (size_t)b * HW;                 // pixel offset of batch item b
+  const int2* __restrict__ stab = shift + (size_t)img * (gridDim.x * gridDim.y);
+  const int2 mine = stab[ty * tiles_x + tx];
+  const int x0 = tx * STW, y0 = ty * STH;
+  const int x1 = min(x0 + STW, d.W), y1 = min(y0 + STH, d.H);
+  // scan window clipped to the image
+  const int sxl = max(x0 - mine.x - SR, 0), sxh = min(x0 - mine.x + STW + SR, d.W);
+  const int syl = max(y0 - mine.y - SR, 0), syh = min(y0 - mine.y + STH + SR, d.H);
+  const int RW = max(sxh - sxl, 0), RH = max(syh - syl, 0);
+  const int n_scan = RW * RH;
+  const bool home_covered = (RW > 0 && RH > 0 && sxl <= x0 && sxh >= x1 && syl <= y0 && syh >= y1);
+  const int n_all = n_scan + (home_covered ? 0 : TP);
+  const float inv_rw = RW > 0 ? 1.0f / (float)RW : 0.0f;
+  for (int k = threadIdx.x; k < 4 * TP; k += kBlock) acc[k] = 0.0;
+  __syncthreads();
+
+  const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
+  const size_t imgpix = (size_t)b * HW;              // pixel offset of batch item b
   const size_t sb = ((size_t)s * d.B + b) * HW;      // pixel offset of (s, b)
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
-  for (int i = 0; i < d.N; ++i) {
-    const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-    float* accb = Acc + (((size_t)s * d.N + i) * d.B + b) * HW * 4;
-    for (int it = 0; it < kLossPPT; ++it) {
-      const int p = (blockIdx.x * kLossPPT + it) * kBlock + threadIdx.x;
-      if (p >= HW) break;
-      const int v = p / d.W, u = p - v * d.W;
-      const float dep = depth[sb + p];
-      const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
-      const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, true, t.x, t.y, t.z);
-      const Corners c = corners(g.x, g.y, xmax, ymax);
-      const int i00 = c.y0 * d.W + c.x0, i01 = c.y1 * d.W + c.x0, i10 = c.y0 * d.W + c.x1, i11 = c.y1 * d.W + c.x1;
-      if (i < ng) {  // gather (utils.py:297-335)
-        const float wx0 = c.fx1 - g.x, wx1 = g.x - c.fx0, wy0 = c.fy1 - g.y, wy1 = g.y - c.fy0;
-        const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
-        const float* sbase = src + img * C3 + 3 * i;
-        const f3 a = ld3(sbase + (size_t)i00 * C3), bb = ld3(sbase + (size_t)i01 * C3);
-        const f3 cc = ld3(sbase + (size_t)i10 * C3), dd = ld3(sbase + (size_t)i11 * C3);
-        st3(G + ((((size_t)s * ng + i) * d.B + b) * HW + p) * 3,
-            ((w00 * a.x + w01 * bb.x) + w10 * cc.x) + w11 * dd.x,
-            ((w00 * a.y + w01 * bb.y) + w10 * cc.y) + w11 * dd.y,
-            ((w00 * a.z + w01 * bb.z) + w10 * cc.z) + w11 * dd.z);
-      }
-      // splat (utils.py:396-468)
-      const SplatW sw = splat_weights(g.x, g.y, c, true, g.z);
-      const f3 tv = ld3(tgt + (img + p) * 3);
-      const int idx[4] = {i00, i01, i10, i11};
+  float* __restrict__ ovf = Ovf + (size_t)img * HW * 4;
+  bool flagged = false;
+
+  for (int k = threadIdx.x; k < n_all; k += kBlock) {
+    int u, v;
+    bool scan;
+    if (k < n_scan) {
+      const int ly = (int)(((float)k + 0.5f) * inv_rw);
+      u = sxl + (k - ly * RW);
+      v = syl + ly;
+      scan = true;
+    } else {  // home pixels the window does not cover (|shift| > SR)
+      const int kk = k - n_scan;
+      u = x0 + (kk & (STW - 1));
+      v = y0 + (kk / STW);
+      if (u >= x1 || v >= y1) continue;
+      if (u >= sxl && u < sxh && v >= syl && v < syh) continue;
+      scan = false;
+    }
+    const bool home = (u >= x0 && u < x1 && v >= y0 && v < y1);
+    const int p = v * d.W + u;
+    const float dep = depth[sb + p];
+    const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
+    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, true, t.x, t.y, t.z);
+    const Corners c = corners(g.x, g.y, xmax, ymax);
+    const SplatW sw = splat_weights(g.x, g.y, c, true, g.z);
+    const f3 tv = ld3(tgt + (imgpix + p) * 3);
+    const int cx[4] = {c.x0, c.x0, c.x1, c.x1}, cy[4] = {c.y0, c.y1, c.y0, c.y1};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float* a = accb + (size_t)idx[k] * 4;
-        atomicAdd(a + 0, tv.x * sw.g[k]);
-        atomicAdd(a + 1, tv.y * sw.g[k]);
-        atomicAdd(a + 2, tv.z * sw.g[k]);
-        atomicAdd(a + 3, sw.g[k]);
+    for (int q = 0; q < 4; ++q) {
+      const float w = sw.g[q];
+      if (scan) {
+        const int lx = cx[q] - x0, ly = cy[q] - y0;
+        if ((unsigned)lx < (unsigned)STW && (unsigned)ly < (unsigned)STH && !(dbg & 1)) {
+          const int l = ly * STW + lx;
+          atomicAdd(&acc[l], (double)(tv.x * w));
+          atomicAdd(&acc[TP + l], (double)(tv.y * w));
+          atomicAdd(&acc[2 * TP + l], (double)(tv.z * w));
+          atomicAdd(&acc[3 * TP + l], (double)w);
+        }
+      }
+      if (home && !(dbg & 2)) {
+        const int dtx = cx[q] / STW, dty = cy[q] / STH;
+        const int2 sft = stab[dty * tiles_x + dtx];
+        if (!in_scan_window(u, v, dtx, dty, sft)) {
+          float* o = ovf + ((size_t)cy[q] * d.W + cx[q]) * 4;
+          atomicAdd(o + 0, tv.x * w);
+          atomicAdd(o + 1, tv.y * w);
+          atomicAdd(o + 2, tv.z * w);
+          atomicAdd(o + 3, w);
+          flagged = true;
+        }
       }
     }
+    if (home && i < ng && !(dbg & 4)) {  // gather (utils.py:297-335)
+      const int i00 = c.y0 * d.W + c.x0, i01 = c.y1 * d.W + c.x0, i10 = c.y0 * d.W + c.x1, i11 = c.y1 * d.W + c.x1;
+      const float wx0 = c.fx1 - g.x, wx1 = g.x - c.fx0, wy0 = c.fy1 - g.y, wy1 = g.y - c.fy0;
+      const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
+      const float* sbase = src + imgpix * C3 + 3 * i;
+      const f3 a = ld3(sbase + (size_t)i00 * C3), bb = ld3(sbase + (size_t)i01 * C3);
+      const f3 cc = ld3(sbase + (size_t)i10 * C3), dd = ld3(sbase + (size_t)i11 * C3);
+      st3(G + ((((size_t)s * ng + i) * d.B + b) * HW + p) * 3,
+          ((w00 * a.x + w01 * bb.x) + w10 * cc.x) + w11 * dd.x,
+          ((w00 * a.y + w01 * bb.y) + w10 * cc.y) + w11 * dd.y,
+          ((w00 * a.z + w01 * bb.z) + w10 * cc.z) + w11 * dd.z);
+    }
   }
+  if (flagged) flags[img] = 1;
+  __syncthreads();
+  float* __restrict__ accg = Acc + (size_t)img * HW * 4;
+  for (int k = threadIdx.x; k < TP; k += kBlock) {
+    const int u = x0 + (k & (STW - 1)), v = y0 + (k / STW);
+    if (u < x1 && v < y1)
+      *reinterpret_cast<float4*>(accg + ((size_t)v * d.W + u) * 4) =
+          make_float4((float)acc[k], (float)acc[TP + k], (float)acc[2 * TP + k], (float)acc[3 * TP + k]);
+  }
+}
+
+// Zeroes the side accumulator of the images whose flag is raised (grid (blocks, S*N*B)).
+__global__ __launch_bounds__(kBlock) void loss_ovf_clear_kernel(float* __restrict__ Ovf, const int* __restrict__ flags,
+                                                                int HW) {
+  if (!flags[blockIdx.y]) return;
+  float4* o = reinterpret_cast<float4*>(Ovf + (size_t)blockIdx.y * HW * 4);
+  for (int p = blockIdx.x * kBlock + threadIdx.x; p < HW; p += gridDim.x * kBlock) o[p] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------ LDS tile helpers
@@ -147,14 +290,21 @@ __device__ __forceinline__ void load_planes3(const float* __restrict__ base, int
 // Acc region -> normalised splat image Sp = S / (D + 1e-10) (utils.py:463,470) in
 // three planes, plus (optionally) the plane of D + 1e-10.
 template <int HALO>
-__device__ __forceinline__ void load_splat_planes(const float* __restrict__ acc, int H, int W, int x0, int y0,
-                                                  float* __restrict__ pl, float* __restrict__ dpl) {
+__device__ __forceinline__ void load_splat_planes(const float* __restrict__ acc, const float* __restrict__ ovf, int H,
+                                                  int W, int x0, int y0, float* __restrict__ pl,
+                                                  float* __restrict__ dpl) {
   using T = Tile<HALO>;
   for (int k = threadIdx.x; k < T::LP; k += kBlock) {
     const int ly = k / T::LW, lx = k - ly * T::LW;
     const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) a = *reinterpret_cast<const float4*>(acc + ((size_t)gy * W + gx) * 4);
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      a = *reinterpret_cast<const float4*>(acc + ((size_t)gy * W + gx) * 4);
+      if (ovf) {  // image with overflow contributions (block-uniform)
+        const float4 o = *reinterpret_cast<const float4*>(ovf + ((size_t)gy * W + gx) * 4);
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+    }
     const float den = a.w + 1e-10f;
     pl[k] = a.x / den;
     pl[T::LP + k] = a.y / den;
@@ -223,7 +373,9 @@ __device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v <
 __global__ __launch_bounds__(kBlock) void loss_stencil_fwd_kernel(const float* __restrict__ tgt,
                                                                   const float* __restrict__ src,
                                                                   const float* __restrict__ G,
-                                                                  const float* __restrict__ Acc, LossDims d,
+                                                                  const float* __restrict__ Acc,
+                                                                  const float* __restrict__ Ovf,
+                                                                  const int* __restrict__ flags, LossDims d,
                                                                   float* __restrict__ blkp) {
   using T = Tile<1>;
   __shared__ float lds[9 * T::LP + 4 * kTerms];
@@ -241,7 +393,9 @@ __global__ __launch_bounds__(kBlock) void loss_stencil_fwd_kernel(const float* _
   for (int k = 0; k < kTerms; ++k) sums[k] = 0.0f;
 
   for (int i = 0; i < d.N; ++i) {
-    load_splat_planes<1>(Acc + (((size_t)s * d.N + i) * d.B + b) * HW * 4, d.H, d.W, x0, y0, P, nullptr);
+    const size_t abase = (((size_t)s * d.N + i) * d.B + b) * HW * 4;
+    load_splat_planes<1>(Acc + abase, flags[(s * d.N + i) * d.B + b] ? Ovf + abase : nullptr, d.H, d.W, x0, y0, P,
+                         nullptr);
     load_planes3<1>(src + (size_t)b * HW * C3 + 3 * i, C3, d.H, d.W, x0, y0, Q);
     __syncthreads();
     float sa = 0.f, sm = 0.f, sv = 0.f;
@@ -353,6 +507,8 @@ __global__ __launch_bounds__(kBlock) void loss_stencil_bwd_kernel(const float* _
                                                                   const float* __restrict__ src,
                                                                   const float* __restrict__ G,
                                                                   const float* __restrict__ Acc,
+                                                                  const float* __restrict__ Ovf,
+                                                                  const int* __restrict__ flags,
                                                                   const float* __restrict__ coef, LossDims d,
                                                                   float* __restrict__ Hb, float* __restrict__ dG) {
   using T = Tile<2>;
@@ -374,7 +530,8 @@ __global__ __launch_bounds__(kBlock) void loss_stencil_bwd_kernel(const float* _
     for (int i = 0; i < d.N; ++i) {
       const float kL1 = coef[1 + 2 * (s * d.N + i)], kV = coef[2 + 2 * (s * d.N + i)];
       const size_t abase = (((size_t)s * d.N + i) * d.B + b) * HW * 4;
-      load_splat_planes<2>(Acc + abase, d.H, d.W, x0, y0, P, Dp);
+      load_splat_planes<2>(Acc + abase, flags[(s * d.N + i) * d.B + b] ? Ovf + abase : nullptr, d.H, d.W, x0, y0, P,
+                           Dp);
       load_planes3<2>(src + (size_t)b * HW * C3 + 3 * i, C3, d.H, d.W, x0, y0, Q);
       __syncthreads();
       // SSIM derivative coefficients on the tile + 1 ring (zero outside the image)
@@ -511,7 +668,8 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
                                                                const float* __restrict__ dG, LossDims d, float step_x,
                                                                float step_y, float* __restrict__ d_depth,
                                                                float* __restrict__ d_trans,
-                                                               float* __restrict__ dPp) {
+                                                               float* __restrict__ dPp, float* __restrict__ Ovf,
+                                                               const int* __restrict__ flags) {
   __shared__ float red[4 * 12];
   const int b = blockIdx.y, s = blockIdx.z;
   const int HW = d.H * d.W, C3 = 3 * d.N;
@@ -525,6 +683,9 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
   for (int i = 0; i < d.N; ++i) {
     const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
     const float* hb = Hb + (((size_t)s * d.N + i) * d.B + b) * HW * 4;
+    // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
+    float4* ovz = flags[(s * d.N + i) * d.B + b]
+                      ? reinterpret_cast<float4*>(Ovf + (((size_t)s * d.N + i) * d.B + b) * HW * 4) : nullptr;
     float dp[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) dp[k] = 0.0f;
@@ -532,6 +693,7 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
     for (int it = 0; it < kLossPPT; ++it) {
       const int p = (blockIdx.x * kLossPPT + it) * kBlock + threadIdx.x;
       if (p < HW) {
+        if (ovz) ovz[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int v = p / d.W, u = p - v * d.W;
         const float dep = depth[sb + p];
         const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
@@ -584,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
 // Optional measurement aid for bench.py: when enabled, the two loss entry points bracket
 // each launch with HIP events on the caller's stream.  Off by default (no events, no
 // overhead); process-wide, not thread-safe - a bench facility, not part of the data path.
-enum { ST_MEMSET = 0, ST_WARP_FWD, ST_STENCIL_FWD, ST_REDUCE, ST_FINALIZE, ST_STENCIL_BWD, ST_WARP_BWD, ST_POSE_GRAD,
+enum { ST_SHIFT = 0, ST_WARP_FWD, ST_STENCIL_FWD, ST_REDUCE, ST_FINALIZE, ST_STENCIL_BWD, ST_WARP_BWD, ST_POSE_GRAD,
        ST_COUNT };
 static bool g_prof_on = false;
 static hipEvent_t g_ev[ST_COUNT][2];
@@ -604,7 +766,7 @@ struct StageTimer {
 
 static inline bool dims_ok(const LossDims& d) {
   return d.B > 0 && d.H > 0 && d.W > 0 && d.S > 0 && d.N >= 2 && d.N <= kMaxSrc && d.B <= 65535 && d.S <= 65535 &&
-         (long)d.S * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 4 ? 3 * d.N : 4);
+         (long)d.S * d.N * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 4 ? 3 * d.N : 4);
 }
 
 }  // namespace sfm
@@ -628,6 +790,20 @@ extern "C" int sfm_loss_num_partials(int B, int H, int W, int S, int N) {
   return S * (3 * N + 1);
 }
 
+// Establishes the invariant both calls below rely on and restore: the side accumulator Ovf and
+// the per-image overflow flags are all zero between steps.  Call once on a fresh workspace (and
+// again after a failed call).
+extern "C" int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, int N, void* stream_) {
+  LossDims d{B, H, W, S, N};
+  if (!ws || !dims_ok(d)) return SFM_ERR_ARG;
+  const LossWs w = loss_ws(d);
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(ws + w.Ovf, 0, (size_t)S * N * B * H * W * 4 * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(ws + w.flags, 0, (size_t)w.n_img * sizeof(int), stream);
+  return e == hipSuccess ? SFM_OK : (int)e;
+}
+
 extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
                                 const float* params, float* ws, int B, int H, int W, int S, int N, double* partials,
                                 void* stream_) {
@@ -635,18 +811,19 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
   if (!tgt || !src || !depth || !trans || !params || !ws || !partials || !dims_ok(d)) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_ws(d);
-  const size_t npx = (size_t)B * H * W;
-  {
-    StageTimer t(ST_MEMSET, stream);
-    hipError_t e = hipMemsetAsync(ws + w.Acc, 0, (size_t)S * N * npx * 4 * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
-  }
+  int2* shift = reinterpret_cast<int2*>(ws + w.shift);
+  int* flags = reinterpret_cast<int*>(ws + w.flags);
+  { StageTimer t(ST_SHIFT, stream);
+  const long n = (long)w.n_img * w.stiles_x * w.stiles_y;
+  hipLaunchKernelGGL(loss_tile_shift_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, depth,
+                     trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift); }
   { StageTimer t(ST_WARP_FWD, stream);
-  hipLaunchKernelGGL(loss_warp_fwd_kernel, dim3(w.nblk_bwd, B, S), dim3(kBlock), 0, stream, tgt, src, depth, trans,
-                     params, d, sfm_lin_step(W), sfm_lin_step(H), ws + w.G, ws + w.Acc); }
+  hipLaunchKernelGGL(loss_splat_tile_kernel, dim3(w.stiles_x, w.stiles_y, w.n_img), dim3(kBlock), 0, stream, tgt, src,
+                     depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
+                     flags, getenv("SFM_DBG") ? atoi(getenv("SFM_DBG")) : 0); }
   { StageTimer t(ST_STENCIL_FWD, stream);
   hipLaunchKernelGGL(loss_stencil_fwd_kernel, dim3(w.tiles_x, w.tiles_y, S * B), dim3(kBlock), 0, stream, tgt, src,
-                     ws + w.G, ws + w.Acc, d, ws + w.blkp); }
+                     ws + w.G, ws + w.Acc, ws + w.Ovf, flags, d, ws + w.blkp); }
   { StageTimer t(ST_REDUCE, stream);
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(S), dim3(kBlock), 0, stream, ws + w.blkp, B * w.tiles_x * w.tiles_y, N,
                      partials); }
@@ -664,25 +841,33 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   if (!tgt || !src || !depth || !trans || !params || !ws || !partials || !loss_out || n_elem_global <= 0 ||
       !dims_ok(d))
     return SFM_ERR_ARG;
+  if (need_grad && (!pose || !K || !d_depth || !d_trans || !d_pose)) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_ws(d);
+  int* flags = reinterpret_cast<int*>(ws + w.flags);
   { StageTimer t(ST_FINALIZE, stream);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, gloss,
                      ws + w.coef, loss_out); }
-  if (!need_grad) return sfm_last_error();
-  if (!pose || !K || !d_depth || !d_trans || !d_pose) return SFM_ERR_ARG;
+  if (!need_grad) {  // forward-only step: restore the Ovf / flags invariant here
+    hipLaunchKernelGGL(loss_ovf_clear_kernel, dim3(64, w.n_img), dim3(kBlock), 0, stream, ws + w.Ovf, flags, H * W);
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_img * sizeof(int), stream);
+    return e != hipSuccess ? (int)e : sfm_last_error();
+  }
   { StageTimer t(ST_STENCIL_BWD, stream);
   hipLaunchKernelGGL(loss_stencil_bwd_kernel, dim3(w.tiles_x, w.tiles_y, S * B), dim3(kBlock), 0, stream, tgt, src,
-                     ws + w.G, ws + w.Acc, ws + w.coef, d, ws + w.Hb, ws + w.dG); }
+                     ws + w.G, ws + w.Acc, ws + w.Ovf, flags, ws + w.coef, d, ws + w.Hb, ws + w.dG); }
   { StageTimer t(ST_WARP_BWD, stream);
   hipLaunchKernelGGL(loss_warp_bwd_kernel, dim3(w.nblk_bwd, B, S), dim3(kBlock), 0, stream, tgt, src, depth, trans,
                      params, ws + w.Hb, ws + w.dG, d, sfm_lin_step(W), sfm_lin_step(H), d_depth, d_trans,
-                     ws + w.dPp); }
+                     ws + w.dPp, ws + w.Ovf, flags); }
   int rc = sfm_last_error();
   if (rc) return rc;
   // pose [B,N,6]: element (b,i,k) at b*6N + i*6 + k; partial sets = scales
   StageTimer t(ST_POSE_GRAD, stream);
-  return sfm_pose_grad(pose, 6L * N, 6L, K, ws + w.dPp, S, w.nblk_bwd, B, N, 0, 1.0f, d_pose, 6L * N, 6L, stream_);
+  rc = sfm_pose_grad(pose, 6L * N, 6L, K, ws + w.dPp, S, w.nblk_bwd, B, N, 0, 1.0f, d_pose, 6L * N, 6L, stream_);
+  if (rc) return rc;
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_img * sizeof(int), stream);  // Ovf was re-zeroed by warp_bwd
+  return e == hipSuccess ? SFM_OK : (int)e;
 }
 
 // ---- measurement aid (bench.py): per-launch HIP-event timing of the two calls above ----
@@ -703,7 +888,7 @@ extern "C" int sfm_prof_enable(int on) {
 extern "C" int sfm_prof_stages(void) { return ST_COUNT; }
 
 // Adds the elapsed milliseconds of the last step's launches into ms[ST_COUNT]; the
-// caller must have synchronised the stream.  Stage order: memset, warp_fwd, stencil_fwd,
+// caller must have synchronised the stream.  Stage order: tile_shift, warp_fwd, stencil_fwd,
 // reduce, finalize, stencil_bwd, warp_bwd, pose_grad.
 extern "C" int sfm_prof_read(float* ms) {
   if (!g_ev_made || !ms) return SFM_ERR_ARG;

@@ -111,25 +111,43 @@ __global__ void pose_setup_kernel(const float* __restrict__ pose, long pose_sb, 
 }
 
 // dL/dP block partials [n_sets][items][nblk][12]  ->  d_pose (b, i, 0..5) at d_pose[b*sb + i*si + k].
-// The n_sets slabs (the scales of the fused loss) and the nblk block partials are
-// summed in a fixed order in fp64, so the result is bitwise reproducible.
-__global__ void pose_grad_kernel(const float* __restrict__ pose, long pose_sb, long pose_si,
-                                 const float* __restrict__ K, const float* __restrict__ partials, int n_sets,
-                                 int nblk, int B, int n_src, int inverse_pose, float gscale,
-                                 float* __restrict__ d_pose, long dpose_sb, long dpose_si) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= B * n_src) return;
-  int i = j / B, b = j - i * B;
+// One 256-thread workgroup per item.  The n_sets slabs (the scales of the fused loss) and the
+// nblk block partials are summed in fp64 in a fixed order (strided per thread, then a fixed
+// shuffle / LDS tree), so the result is bitwise reproducible; thread 0 applies the chain rule.
+__global__ __launch_bounds__(kBlock) void pose_grad_kernel(const float* __restrict__ pose, long pose_sb, long pose_si,
+                                                           const float* __restrict__ K,
+                                                           const float* __restrict__ partials, int n_sets, int nblk,
+                                                           int B, int n_src, int inverse_pose, float gscale,
+                                                           float* __restrict__ d_pose, long dpose_sb, long dpose_si) {
+  __shared__ double red[4][12];
+  const int j = blockIdx.x;
+  const int i = j / B, b = j - i * B;
   const float* pv = pose + b * pose_sb + i * pose_si;
   const float* k3 = K + (long)b * 9;
   double dP[12];
   for (int k = 0; k < 12; ++k) dP[k] = 0.0;
   const long items = (long)B * n_src;
-  for (int s = 0; s < n_sets; ++s) {
-    const float* pp = partials + (((long)s * items + j) * nblk) * 12;
-    for (int q = 0; q < nblk; ++q)
-      for (int k = 0; k < 12; ++k) dP[k] += (double)pp[(long)q * 12 + k];
+  const int rows = n_sets * nblk;
+  for (int r = threadIdx.x; r < rows; r += kBlock) {
+    const int s = r / nblk, q = r - s * nblk;
+    const float* pp = partials + ((((long)s * items + j) * nblk) + q) * 12;
+    const float4 a = *reinterpret_cast<const float4*>(pp), bq = *reinterpret_cast<const float4*>(pp + 4),
+                 c = *reinterpret_cast<const float4*>(pp + 8);
+    dP[0] += (double)a.x; dP[1] += (double)a.y; dP[2] += (double)a.z; dP[3] += (double)a.w;
+    dP[4] += (double)bq.x; dP[5] += (double)bq.y; dP[6] += (double)bq.z; dP[7] += (double)bq.w;
+    dP[8] += (double)c.x; dP[9] += (double)c.y; dP[10] += (double)c.z; dP[11] += (double)c.w;
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    double v = dP[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < 12; ++k) dP[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
   // dTm[r][c] = sum_k K[k][r] dP[k][c]   (rows 0..2; row 3 of K4 only feeds q3, unused)
   double dTm[16];
   for (int r = 0; r < 3; ++r)
@@ -230,7 +248,7 @@ extern "C" int sfm_pose_grad(const float* pose, long pose_sb, long pose_si, cons
                              long dpose_sb, long dpose_si, void* stream) {
   if (!pose || !K || !partials || !d_pose || B <= 0 || n_src <= 0 || nblk <= 0 || n_sets <= 0) return SFM_ERR_ARG;
   int items = B * n_src;
-  hipLaunchKernelGGL(pose_grad_kernel, dim3((items + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, pose_sb,
-                     pose_si, K, partials, n_sets, nblk, B, n_src, inverse_pose, gscale, d_pose, dpose_sb, dpose_si);
+  hipLaunchKernelGGL(pose_grad_kernel, dim3(items), dim3(kBlock), 0, (hipStream_t)stream, pose, pose_sb, pose_si, K,
+                     partials, n_sets, nblk, B, n_src, inverse_pose, gscale, d_pose, dpose_sb, dpose_si);
   return sfm_last_error();
 }

@@ -40,6 +40,15 @@ class LossEngine:
         with torch.cuda.device(self.device):
             self.ws = torch.empty(n, dtype=torch.float32, device=self.device)
             self.params = torch.empty(N * B, _lib.PARAM_STRIDE, dtype=torch.float32, device=self.device)
+            call("sfm_loss_workspace_init", ptr(self.ws), B, H, W, S, N, stream_of(self.ws))
+
+    def overflow_state(self):
+        """(number of raised overflow flags, max |Ovf|) - both 0 between steps (test / debug aid)."""
+        B, H, W, S, N = self.dims
+        n_acc = S * N * B * H * W * 4
+        ovf = self.ws[n_acc:2 * n_acc]                       # workspace map of csrc/loss.hip: Acc, Ovf, ...
+        flags = self.ws[-((S * N * B + 3) // 4 * 4):].view(torch.int32)[:S * N * B]
+        return int((flags != 0).sum()), float(ovf.abs().max())
 
     def forward_partials(self, tgt, src, K, depth, pose, trans) -> Tensor:
         B, H, W, S, N = self.dims

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (on the GPU box): tools/prof.sh <tag>   -> gpurun_out/prof_<tag>/ + printed per-kernel averages
+set -e
+tag=${1:-x}
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+rm -rf $out
+timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out.log 2>&1
+f=$(find $out -name "*kernel_stats.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:12]:
+    print(f"{r['Name'][:60]:60s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:9.2f}  {float(r['Percentage']):6.2f}%")
+PY
+grep '"metric"' $out.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], 'value', d['value'], d['roofline']['stage_us'])"
