@@ -35,9 +35,8 @@ sys.path.insert(0, ROOT)
 
 H, W, B, S, N = 128, 416, 8, 4, 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-STAGES = ["tile_shift", "warp_fwd", "stencil_fwd", "reduce", "finalize", "stencil_bwd", "warp_bwd", "pose_grad"]
-KERNEL_OF = {"warp_fwd": "loss_splat_tile_kernel", "stencil_fwd": "loss_stencil_fwd_kernel",
-             "stencil_bwd": "loss_stencil_bwd_kernel", "warp_bwd": "loss_warp_bwd_kernel"}
+STAGES = ["tile_shift", "warp_fwd", "stencil", "reduce", "finalize", "warp_bwd", "pose_grad"]
+KERNEL_OF = {"warp_fwd": "loss_splat_tile_kernel", "stencil": "loss_stencil_kernel", "warp_bwd": "loss_warp_bwd_kernel"}
 
 
 def algorithmic_bytes(n_src: int) -> dict:
@@ -45,9 +44,8 @@ def algorithmic_bytes(n_src: int) -> dict:
     n, g = n_src, min(n_src, 2)
     return {
         "warp_fwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 16 * n,   # depth, tgt, trans, src taps; G out, Acc out
-        "stencil_fwd": 16 * n + 12 * n + 12 * g + 12,         # Acc, src, G, tgt
-        "stencil_bwd": 16 * n + 12 * n + 12 * g + 12 + 16 * n + 12 * g,   # + Hb out, dG out
-        "warp_bwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 16 * n + 4 + 12 * n,  # + dG, Hb in; d_depth, d_trans out
+        "stencil": 16 * n + 12 * n + 12 * g + 12 + 32 * n + 12 * g,   # Acc, src, G, tgt in; Hb (2 parts), dG out
+        "warp_bwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 32 * n + 4 + 12 * n,  # + dG, Hb in; d_depth, d_trans out
     }
 
 
@@ -114,7 +112,7 @@ def main() -> None:
     n_elem_global = world * B * H * W * 3
 
     def step():
-        partials = eng.forward_partials(tgt, src, K, depth, pose, trans)
+        partials = eng.forward_partials(tgt, src, K, depth, pose, trans, n_elem_global, True)
         if world > 1:
             dist.all_reduce(partials)
         return eng.backward(tgt, src, K, depth, pose, trans, partials, n_elem_global, 1.0, True)

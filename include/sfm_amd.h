@@ -109,6 +109,10 @@ int sfm_ssim_bwd(const float* img1, const float* img2, const float* gv, int B, i
  * Each sfm_loss_forward must be followed by sfm_loss_backward on the same ws (need_grad 0 or 1)
  * before the next sfm_loss_forward; calls sharing a ws must be stream-ordered.
  *
+ * n_elem_global = B_global*H*W*3 is the denominator of every reduce_mean of the loss (the
+ * batch is global under data parallelism); need_grad = 0 makes sfm_loss_forward skip the
+ * backward seeds (it must then be paired with sfm_loss_backward(need_grad = 0)).
+ *
  * sfm_loss_forward writes partials[S*(3N+1)] (fp64): per scale, per source the sums
  * (sum m|Sp-src|, sum m, sum ssim(Sp,src)) and then sum min(e_0,e_1).  Under data
  * parallelism these are all-reduced (sum) across ranks before sfm_loss_backward; that is
@@ -120,8 +124,8 @@ long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N);
 int sfm_loss_num_partials(int B, int H, int W, int S, int N);
 int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, int N, void* stream);
 int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
-                     const float* params, float* ws, int B, int H, int W, int S, int N, double* partials,
-                     void* stream);
+                     const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
+                     int need_grad, double* partials, void* stream);
 int sfm_loss_backward(const float* tgt, const float* src, const float* depth, const float* trans,
                       const float* params, float* ws, int B, int H, int W, int S, int N,
                       long long n_elem_global, float gloss, int need_grad, const double* partials,
@@ -131,8 +135,8 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
 /* ---- measurement aid (no counterpart in the reference; used by bench.py only) -----------
  * When enabled, sfm_loss_forward / sfm_loss_backward bracket each of their launches with
  * HIP events on the caller's stream; sfm_prof_read adds the last step's elapsed ms per stage
- * into ms[sfm_prof_stages()] (order: tile_shift, warp_fwd, stencil_fwd, reduce, finalize,
- * stencil_bwd, warp_bwd, pose_grad) after the caller synchronised.  Process-wide, off by default. */
+ * into ms[sfm_prof_stages()] (order: tile_shift, warp_fwd, stencil, reduce, finalize,
+ * warp_bwd, pose_grad) after the caller synchronised.  Process-wide, off by default. */
 int sfm_prof_enable(int on);
 int sfm_prof_stages(void);
 int sfm_prof_read(float* ms);

@@ -40,7 +40,7 @@ SIGNATURES = {
     "sfm_loss_workspace_floats": [_I, _I, _I, _I, _I],
     "sfm_loss_num_partials": [_I, _I, _I, _I, _I],
     "sfm_loss_workspace_init": [_P, _I, _I, _I, _I, _I, _P],
-    "sfm_loss_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "sfm_loss_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
     "sfm_prof_enable": [_I],
     "sfm_prof_stages": [],
     "sfm_prof_read": [_P],

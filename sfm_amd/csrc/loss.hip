@@ -1,13 +1,15 @@
 // Fused multi-scale photometric loss of SfMLearner_uni.py:85-168, forward and backward,
 // for S scales x N sources in a fixed number of launches (independent of S and N):
 //
-//   forward   memset(Acc) -> warp_fwd -> stencil_fwd -> reduce_partials      (sfm_loss_forward)
-//   backward  finalize -> stencil_bwd -> warp_bwd -> pose_grad               (sfm_loss_backward)
+//   sfm_loss_forward    tile_shift -> splat_tile (both warps) -> stencil (loss_stencil.hip) -> reduce
+//   sfm_loss_backward   finalize -> warp_bwd -> pose_grad
 //
 // Between the two halves sits the only cross-GPU exchange of the data-parallel path:
 // an all-reduce of the S*(3N+1) fp64 partial sums; tf_ssim's
 // global mean (utils.py:573-575) is taken before its non-linear clip, so the sums
-// must be global before the backward coefficients exist.
+// must be global before the backward coefficient of the SSIM part exists.  The stencil
+// kernel therefore writes the backward seeds in two parts (see loss_stencil.hip) and the
+// backward warp combines them with the coefficients loss_finalize_kernel derives.
 //
 // Per (scale s, source i), reference lines in SfMLearner_uni.py:
 //   G_i      = projective_inverse_warp(src_i, depth_s, pose_i, K, trans_si)          :120
@@ -18,62 +20,18 @@
 // Both warps of a pair share one geometry (utils.py:185-202 == 220-237), so it is
 // evaluated once per pixel and source; meshgrid / cam / coords never exist in memory.
 //
-// Data layout in HBM (all fp32, NHWC):
+// Data layout in HBM (all fp32, NHWC; workspace map in loss_common.h):
 //   tgt [B,H,W,3]   src [B,H,W,3N]   depth [S,B,H,W]   trans [S,B,H,W,3N]
 //   G   [S,2,B,H,W,3]     gathered sources 0,1 (the only ones line 168 reads)
 //   Acc [S,N,B,H,W,4]     splat accumulators (sum g*rgb, sum g): one 16-B unit per pixel
-//   Hb  [S,N,B,H,W,4]     backward: (gout/D', sum_c gout*Sp/D') per destination pixel
-//   dG  [S,2,B,H,W,3]     backward: dL/dG_i
-#include "sfm_device.h"
-#include "sfm_internal.h"
+//   Hb  [S,N,B,H,W,8]     backward seeds per destination pixel, two parts (hA[3], sum_c hA*Sp, hB[3], sum_c hB*Sp)
+//   dG  [S,2,B,H,W,3]     backward: dL/dG_i for gloss = 1
+#include "loss_common.h"
 #include <cstdlib>
 
 namespace sfm {
 
-constexpr int kMaxSrc = 4;
-constexpr int kTerms = 3 * kMaxSrc + 1;  // block partial slots: (A,M,V) per source, then E
-constexpr int TW = 32, TH = 16;          // stencil tile (pixels) per 256-thread block
-constexpr int kLossPPT = 4;              // pixels per thread in the streaming warp kernels
-constexpr int STW = 64, STH = 16;        // splat: destination tile of one workgroup (LDS: 4 fp64 planes x 8 KiB)
-constexpr int SR = 8;                    // splat: reach of the scan window around the shifted tile
-constexpr float kAlpha = 0.15f;          // SfMLearner_uni.py:84
-
-struct LossDims {
-  int B, H, W, S, N;
-};
-
-// ------------------------------------------------------------------ workspace map
-struct LossWs {
-  size_t G, Acc, Ovf, Hb, dG, blkp, dPp, coef, shift, flags, total;
-  int tiles_x, tiles_y, nblk_bwd, stiles_x, stiles_y, n_img;
-};
-
-static inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
-
-static LossWs loss_ws(const LossDims& d) {
-  LossWs w;
-  const size_t npx = (size_t)d.B * d.H * d.W;
-  const int ng = d.N < 2 ? d.N : 2;
-  w.tiles_x = (d.W + TW - 1) / TW;
-  w.tiles_y = (d.H + TH - 1) / TH;
-  w.nblk_bwd = (d.H * d.W + kBlock * kLossPPT - 1) / (kBlock * kLossPPT);
-  w.stiles_x = (d.W + STW - 1) / STW;
-  w.stiles_y = (d.H + STH - 1) / STH;
-  w.n_img = d.S * d.N * d.B;
-  size_t o = 0;
-  w.Acc = o; o += (size_t)d.S * d.N * npx * 4;
-  w.Ovf = o; o += (size_t)d.S * d.N * npx * 4;
-  w.Hb = o;  o += (size_t)d.S * d.N * npx * 4;
-  w.G = o;   o += up4((size_t)d.S * ng * npx * 3);
-  w.dG = o;  o += up4((size_t)d.S * ng * npx * 3);
-  w.blkp = o; o += up4((size_t)d.S * d.B * w.tiles_x * w.tiles_y * kTerms);
-  w.dPp = o; o += up4((size_t)d.S * d.N * d.B * w.nblk_bwd * 12);
-  w.coef = o; o += 64;
-  w.shift = o; o += up4((size_t)w.n_img * w.stiles_x * w.stiles_y * 2);
-  w.flags = o; o += up4((size_t)w.n_img);
-  w.total = o;
-  return w;
-}
+constexpr int SR = 8;  // splat: reach of the scan window around the shifted tile
 
 // ------------------------------------------------------------------ fused warp forward
 // The forward splat (utils.py:419-470) without global atomics in the common case.
@@ -149,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
                                                                  float step_x, float step_y,
                                                                  const int2* __restrict__ shift, float* __restrict__ G,
                                                                  float* __restrict__ Acc, float* __restrict__ Ovf,
-                                                                 int* __restrict__ flags, int dbg) {
+                                                                 int* __restrict__ flags) {
   constexpr int TP = STW * STH;
   // planes: sum g*r, sum g*g, sum g*b, sum g.  fp64 on purpose: on gfx950 ds_add_f64 retires a wave
   // instruction in ~9 cycles while ds_add_f32 takes ~190 (profiles/r01_lds_atomic_microbench.txt);
@@ -212,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
       const float w = sw.g[q];
       if (scan) {
         const int lx = cx[q] - x0, ly = cy[q] - y0;
-        if ((unsigned)lx < (unsigned)STW && (unsigned)ly < (unsigned)STH && !(dbg & 1)) {
+        if ((unsigned)lx < (unsigned)STW && (unsigned)ly < (unsigned)STH) {
           const int l = ly * STW + lx;
           atomicAdd(&acc[l], (double)(tv.x * w));
           atomicAdd(&acc[TP + l], (double)(tv.y * w));
@@ -220,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
           atomicAdd(&acc[3 * TP + l], (double)w);
         }
       }
-      if (home && !(dbg & 2)) {
+      if (home) {
         const int dtx = cx[q] / STW, dty = cy[q] / STH;
         const int2 sft = stab[dty * tiles_x + dtx];
         if (!in_scan_window(u, v, dtx, dty, sft)) {
@@ -233,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
         }
       }
     }
-    if (home && i < ng && !(dbg & 4)) {  // gather (utils.py:297-335)
+    if (home && i < ng) {  // gather (utils.py:297-335)
       const int i00 = c.y0 * d.W + c.x0, i01 = c.y1 * d.W + c.x0, i10 = c.y0 * d.W + c.x1, i11 = c.y1 * d.W + c.x1;
       const float wx0 = c.fx1 - g.x, wx1 = g.x - c.fx0, wy0 = c.fy1 - g.y, wy1 = g.y - c.fy0;
       const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
@@ -265,219 +223,40 @@ __global__ __launch_bounds__(kBlock) void loss_ovf_clear_kernel(float* __restric
   for (int p = blockIdx.x * kBlock + threadIdx.x; p < HW; p += gridDim.x * kBlock) o[p] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// ------------------------------------------------------------------ LDS tile helpers
-template <int HALO>
-struct Tile {
-  static constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO, LP = LW * LH;
-};
-
-// NHWC 3-channel region -> three planes, zero outside the image (SAME padding).
-template <int HALO>
-__device__ __forceinline__ void load_planes3(const float* __restrict__ base, int pix_stride, int H, int W, int x0,
-                                             int y0, float* __restrict__ pl) {
-  using T = Tile<HALO>;
-  for (int k = threadIdx.x; k < T::LP; k += kBlock) {
-    const int ly = k / T::LW, lx = k - ly * T::LW;
-    const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
-    f3 v{0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ld3(base + ((size_t)gy * W + gx) * pix_stride);
-    pl[k] = v.x;
-    pl[T::LP + k] = v.y;
-    pl[2 * T::LP + k] = v.z;
-  }
-}
-
-// Acc region -> normalised splat image Sp = S / (D + 1e-10) (utils.py:463,470) in
-// three planes, plus (optionally) the plane of D + 1e-10.
-template <int HALO>
-__device__ __forceinline__ void load_splat_planes(const float* __restrict__ acc, const float* __restrict__ ovf, int H,
-                                                  int W, int x0, int y0, float* __restrict__ pl,
-                                                  float* __restrict__ dpl) {
-  using T = Tile<HALO>;
-  for (int k = threadIdx.x; k < T::LP; k += kBlock) {
-    const int ly = k / T::LW, lx = k - ly * T::LW;
-    const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      a = *reinterpret_cast<const float4*>(acc + ((size_t)gy * W + gx) * 4);
-      if (ovf) {  // image with overflow contributions (block-uniform)
-        const float4 o = *reinterpret_cast<const float4*>(ovf + ((size_t)gy * W + gx) * 4);
-        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-      }
-    }
-    const float den = a.w + 1e-10f;
-    pl[k] = a.x / den;
-    pl[T::LP + k] = a.y / den;
-    pl[2 * T::LP + k] = a.z / den;
-    if (dpl) dpl[k] = den;
-  }
-}
-
-template <int LW>
-__device__ __forceinline__ void moments_lds(const float* __restrict__ X, const float* __restrict__ Y, int l,
-                                            const SsimWin& win, float& m1, float& m2, float& m11, float& m22,
-                                            float& m12) {
-  m1 = m2 = m11 = m22 = m12 = 0.0f;
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const float w = win.w[(dy + 1) * 3 + (dx + 1)];
-      const float a = X[l + dy * LW + dx], b = Y[l + dy * LW + dx];
-      m1 += w * a;
-      m2 += w * b;
-      m11 += w * (a * a);
-      m22 += w * (b * b);
-      m12 += w * (a * b);
-    }
-}
-
-template <int LW>
-__device__ __forceinline__ float conv3_lds(const float* __restrict__ P, int l, const SsimWin& win) {
-  float s = 0.0f;
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) s += win.w[(dy + 1) * 3 + (dx + 1)] * P[l + dy * LW + dx];
-  return s;
-}
-
-// validity mask of bilinear_project (utils.py:478-479) at one pixel and channel
-template <int LW>
-__device__ __forceinline__ float splat_mask_lds(const float* __restrict__ P, int l, float inv_cnt_num) {
-  float nz = 0.0f;
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) nz += (P[l + dy * LW + dx] == 0.0f) ? 0.0f : 1.0f;
-  return nz / inv_cnt_num;
-}
-
-__device__ __forceinline__ float tap_count(int gy, int gx, int H, int W) {
-  const int ny = min(gy + 1, H - 1) - max(gy - 1, 0) + 1;
-  const int nx = min(gx + 1, W - 1) - max(gx - 1, 0) + 1;
-  return (float)(ny * nx);
-}
-
-__device__ __forceinline__ float clip01_half(float v) {  // clip((1 - v)/2, 0, 1), utils.py:575
-  return fminf(fmaxf((1.0f - v) / 2.0f, 0.0f), 1.0f);
-}
-__device__ __forceinline__ float clip01_half_pass(float v) {  // 1 where the clip passes the gradient
-  const float h = (1.0f - v) / 2.0f;
-  return (h >= 0.0f && h <= 1.0f) ? 1.0f : 0.0f;
-}
-__device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
-
-// ------------------------------------------------------------------ stencil forward
-// grid (tiles_x, tiles_y, S*B).  Per block: partial sums (A_i, M_i, V_i) i<N and E.
-__global__ __launch_bounds__(kBlock) void loss_stencil_fwd_kernel(const float* __restrict__ tgt,
-                                                                  const float* __restrict__ src,
-                                                                  const float* __restrict__ G,
-                                                                  const float* __restrict__ Acc,
-                                                                  const float* __restrict__ Ovf,
-                                                                  const int* __restrict__ flags, LossDims d,
-                                                                  float* __restrict__ blkp) {
-  using T = Tile<1>;
-  __shared__ float lds[9 * T::LP + 4 * kTerms];
-  float* P = lds;               // Sp_i   (3 planes)   | later G_0
-  float* Q = lds + 3 * T::LP;   // src_i  (3 planes)   | later G_1
-  float* R = lds + 6 * T::LP;   // tgt    (3 planes)
-  float* red = lds + 9 * T::LP;
-  const int s = blockIdx.z / d.B, b = blockIdx.z - s * d.B;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int HW = d.H * d.W, C3 = 3 * d.N;
-  const int ng = d.N < 2 ? d.N : 2;
-  const SsimWin win = ssim_window();
-  float sums[kTerms];
-#pragma unroll
-  for (int k = 0; k < kTerms; ++k) sums[k] = 0.0f;
-
-  for (int i = 0; i < d.N; ++i) {
-    const size_t abase = (((size_t)s * d.N + i) * d.B + b) * HW * 4;
-    load_splat_planes<1>(Acc + abase, flags[(s * d.N + i) * d.B + b] ? Ovf + abase : nullptr, d.H, d.W, x0, y0, P,
-                         nullptr);
-    load_planes3<1>(src + (size_t)b * HW * C3 + 3 * i, C3, d.H, d.W, x0, y0, Q);
-    __syncthreads();
-    float sa = 0.f, sm = 0.f, sv = 0.f;
-    for (int k = threadIdx.x; k < TW * TH; k += kBlock) {
-      const int ty = k / TW, tx = k - ty * TW;
-      const int gy = y0 + ty, gx = x0 + tx;
-      if (gy >= d.H || gx >= d.W) continue;
-      const int l = (ty + 1) * T::LW + tx + 1;
-      const float cnt = tap_count(gy, gx, d.H, d.W);
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float* X = P + ch * T::LP;
-        const float* Y = Q + ch * T::LP;
-        float m1, m2, m11, m22, m12;
-        moments_lds<T::LW>(X, Y, l, win, m1, m2, m11, m22, m12);
-        sv += ssim_from_moments(m1, m2, m11, m22, m12);
-        const float m = splat_mask_lds<T::LW>(X, l, cnt);
-        sa += m * fabsf(X[l] - Y[l]);
-        sm += m;
-      }
-    }
-    // static slots: runtime i indexes registers through an unrolled select
-#pragma unroll
-    for (int j = 0; j < kMaxSrc; ++j)
-      if (j == i) { sums[3 * j] += sa; sums[3 * j + 1] += sm; sums[3 * j + 2] += sv; }
-    __syncthreads();
-  }
-  if (ng == 2) {
-    const size_t gpix = (size_t)d.B * HW;
-    load_planes3<1>(G + (((size_t)s * ng + 0) * gpix + (size_t)b * HW) * 3, 3, d.H, d.W, x0, y0, P);
-    load_planes3<1>(G + (((size_t)s * ng + 1) * gpix + (size_t)b * HW) * 3, 3, d.H, d.W, x0, y0, Q);
-    load_planes3<1>(tgt + (size_t)b * HW * 3, 3, d.H, d.W, x0, y0, R);
-    __syncthreads();
-    float se = 0.f;
-    for (int k = threadIdx.x; k < TW * TH; k += kBlock) {
-      const int ty = k / TW, tx = k - ty * TW;
-      const int gy = y0 + ty, gx = x0 + tx;
-      if (gy >= d.H || gx >= d.W) continue;
-      const int l = (ty + 1) * T::LW + tx + 1;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float* Tg = R + ch * T::LP;
-        float m1, m2, m11, m22, m12;
-        moments_lds<T::LW>(P + ch * T::LP, Tg, l, win, m1, m2, m11, m22, m12);
-        const float e0 = kAlpha * fabsf(P[ch * T::LP + l] - Tg[l]) +
-                         (1.0f - kAlpha) * clip01_half(ssim_from_moments(m1, m2, m11, m22, m12));
-        moments_lds<T::LW>(Q + ch * T::LP, Tg, l, win, m1, m2, m11, m22, m12);
-        const float e1 = kAlpha * fabsf(Q[ch * T::LP + l] - Tg[l]) +
-                         (1.0f - kAlpha) * clip01_half(ssim_from_moments(m1, m2, m11, m22, m12));
-        se += (e0 <= e1) ? e0 : e1;
-      }
-    }
-    sums[kTerms - 1] = se;
-  }
-  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  block_sum_store<kTerms>(sums, red, blkp + blk * kTerms);
-}
-
-// block partials [S][B*tiles][kTerms] -> partials fp64 [S][3N+1], fixed summation order.
-__global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __restrict__ blkp, int per_scale, int N,
+// ------------------------------------------------------------------ reduce
+// per-wave partial sums of the stencil kernel -> partials fp64 [S][3N+1], fixed summation order
+// (deterministic).  grid (S, 3N+1): block (s, t) owns one term.
+__global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __restrict__ wavep, LossDims d, StencilPlan p,
                                                              double* __restrict__ partials) {
   __shared__ double red[kBlock];
-  const int s = blockIdx.x;
-  const int nterm = 3 * N + 1;
-  for (int t = 0; t < nterm; ++t) {
-    const int slot = (t < 3 * N) ? t : (kTerms - 1);
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < per_scale; k += kBlock) acc += (double)blkp[((size_t)s * per_scale + k) * kTerms + slot];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = kBlock / 2; o > 0; o >>= 1) {
-      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) partials[(size_t)s * nterm + t] = red[0];
+  const int s = blockIdx.x, t = blockIdx.y;
+  const int nterm = 3 * d.N + 1;
+  const long per = (long)d.B * p.per_img;  // waves per (scale, source) image set
+  long first;
+  int comp;
+  if (t < 3 * d.N) {
+    first = ((long)s * d.N + t / 3) * per;
+    comp = t % 3;
+  } else {
+    first = p.n_splat + (long)s * per;
+    comp = 0;
+  }
+  double acc = 0.0;
+  if (t < 3 * d.N || p.n_gather > 0)
+    for (long k = threadIdx.x; k < per; k += kBlock) acc += (double)wavep[(first + k) * kWaveTerms + comp];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
+  if (threadIdx.x == 0) partials[(size_t)s * nterm + t] = red[0];
 }
 
 // ------------------------------------------------------------------ finalize
-// partials (global sums) -> loss and backward coefficients.
-// coef[0] = kE = g*2/n ; coef[1 + 2*(s*N+i)] = kL1 = g*a/n ; coef[2 + 2*(s*N+i)] = kV.
+// partials (global sums) -> loss and the coefficients the backward warp combines the two parts
+// of Hb with:  coef[0] = gloss ;  coef[1 + s*N + i] = gloss * kV(s, i),
+// kV = (1 - alpha) (M / n) (-1/2) [clip passes] / n   (d/dSp of (1-alpha) mean(m) clip((1 - V/n)/2, 0, 1)).
 __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S, int N, double n_elem, float gloss,
                                      float* __restrict__ coef, float* __restrict__ loss_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -489,171 +268,16 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
       const double A = partials[s * nterm + 3 * i], M = partials[s * nterm + 3 * i + 1],
                    V = partials[s * nterm + 3 * i + 2];
       const float vmean = (float)(V / n_elem);
-      const float sc = clip01_half(vmean);
+      const float h = (1.0f - vmean) / 2.0f;
+      const float sc = fminf(fmaxf(h, 0.0f), 1.0f);
+      const double pass = (h >= 0.0f && h <= 1.0f) ? 1.0 : 0.0;
       loss += a * (A / n_elem) + (1.0 - a) * (double)sc * (M / n_elem);
-      coef[1 + 2 * (s * N + i)] = (float)((double)gloss * a / n_elem);
-      coef[2 + 2 * (s * N + i)] =
-          (float)((double)gloss * (1.0 - a) * (M / n_elem) * (-0.5) * (double)clip01_half_pass(vmean) / n_elem);
+      coef[1 + s * N + i] = (float)((double)gloss * (1.0 - a) * (M / n_elem) * (-0.5) * pass / n_elem);
     }
     loss += 2.0 * partials[s * nterm + 3 * N] / n_elem;
   }
-  coef[0] = (float)((double)gloss * 2.0 / n_elem);
+  coef[0] = gloss;
   *loss_out = (float)loss;
-}
-
-// ------------------------------------------------------------------ stencil backward
-// grid (tiles_x, tiles_y, S*B).  Writes Hb (all sources) and dG (sources 0,1).
-__global__ __launch_bounds__(kBlock) void loss_stencil_bwd_kernel(const float* __restrict__ tgt,
-                                                                  const float* __restrict__ src,
-                                                                  const float* __restrict__ G,
-                                                                  const float* __restrict__ Acc,
-                                                                  const float* __restrict__ Ovf,
-                                                                  const int* __restrict__ flags,
-                                                                  const float* __restrict__ coef, LossDims d,
-                                                                  float* __restrict__ Hb, float* __restrict__ dG) {
-  using T = Tile<2>;
-  constexpr int LW = T::LW, LP = T::LP;
-  __shared__ float lds[16 * LP];
-  const int s = blockIdx.z / d.B, b = blockIdx.z - s * d.B;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int HW = d.H * d.W, C3 = 3 * d.N;
-  const int ng = d.N < 2 ? d.N : 2;
-  const SsimWin win = ssim_window();
-  const float kE = coef[0];
-
-  // ---- splat side: x = Sp_i, y = src_i ----
-  {
-    float* P = lds;             // 3 planes Sp
-    float* Q = lds + 3 * LP;    // 3 planes src
-    float* Dp = lds + 6 * LP;   // D + 1e-10
-    float* CF = lds + 7 * LP;   // 9 planes: a[3], b[3], c[3]
-    for (int i = 0; i < d.N; ++i) {
-      const float kL1 = coef[1 + 2 * (s * d.N + i)], kV = coef[2 + 2 * (s * d.N + i)];
-      const size_t abase = (((size_t)s * d.N + i) * d.B + b) * HW * 4;
-      load_splat_planes<2>(Acc + abase, flags[(s * d.N + i) * d.B + b] ? Ovf + abase : nullptr, d.H, d.W, x0, y0, P,
-                           Dp);
-      load_planes3<2>(src + (size_t)b * HW * C3 + 3 * i, C3, d.H, d.W, x0, y0, Q);
-      __syncthreads();
-      // SSIM derivative coefficients on the tile + 1 ring (zero outside the image)
-      for (int k = threadIdx.x; k < (TW + 2) * (TH + 2); k += kBlock) {
-        const int ry = k / (TW + 2), rx = k - ry * (TW + 2);
-        const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
-        const int l = (ry + 1) * LW + rx + 1;
-        const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float ca = 0.f, cb = 0.f, cc = 0.f;
-          if (in) {
-            float m1, m2, m11, m22, m12;
-            moments_lds<LW>(P + ch * LP, Q + ch * LP, l, win, m1, m2, m11, m22, m12);
-            ssim_with_grad(m1, m2, m11, m22, m12, ca, cb, cc);
-          }
-          CF[ch * LP + l] = ca;
-          CF[(3 + ch) * LP + l] = cb;
-          CF[(6 + ch) * LP + l] = cc;
-        }
-      }
-      __syncthreads();
-      for (int k = threadIdx.x; k < TW * TH; k += kBlock) {
-        const int ty = k / TW, tx = k - ty * TW;
-        const int gy = y0 + ty, gx = x0 + tx;
-        if (gy >= d.H || gx >= d.W) continue;
-        const int l = (ty + 2) * LW + tx + 2;
-        const float cnt = tap_count(gy, gx, d.H, d.W);
-        const float inv = 1.0f / Dp[l];
-        float h[3], hw = 0.0f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float x = P[ch * LP + l], y = Q[ch * LP + l];
-          const float r = conv3_lds<LW>(CF + ch * LP, l, win) + 2.0f * conv3_lds<LW>(CF + (3 + ch) * LP, l, win) * x +
-                          conv3_lds<LW>(CF + (6 + ch) * LP, l, win) * y;
-          const float m = splat_mask_lds<LW>(P + ch * LP, l, cnt);
-          const float go = kL1 * m * sgn(x - y) + kV * r;
-          h[ch] = go * inv;
-          hw += h[ch] * x;
-        }
-        *reinterpret_cast<float4*>(Hb + abase + ((size_t)gy * d.W + gx) * 4) = make_float4(h[0], h[1], h[2], hw);
-      }
-      __syncthreads();
-    }
-  }
-  if (ng < 2) return;
-  // ---- gather side: x = G_0 / G_1, y = tgt; min-selection per (pixel, channel) ----
-  {
-    float* X0 = lds;            // 3 planes
-    float* X1 = lds + 3 * LP;   // 3 planes
-    float* Tg = lds + 6 * LP;   // 3 planes
-    float* CF = lds + 9 * LP;   // per channel: a0,b0,c0,a1,b1,c1 (u-scaled), sel
-    const size_t gpix = (size_t)d.B * HW;
-    const size_t g0 = (((size_t)s * ng + 0) * gpix + (size_t)b * HW) * 3;
-    const size_t g1 = (((size_t)s * ng + 1) * gpix + (size_t)b * HW) * 3;
-    load_planes3<2>(G + g0, 3, d.H, d.W, x0, y0, X0);
-    load_planes3<2>(G + g1, 3, d.H, d.W, x0, y0, X1);
-    load_planes3<2>(tgt + (size_t)b * HW * 3, 3, d.H, d.W, x0, y0, Tg);
-    float o0[2][3], o1[2][3];  // up to 2 owned pixels per thread
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) o0[q][ch] = o1[q][ch] = 0.0f;
-    const float ku = kE * (1.0f - kAlpha) * (-0.5f);
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      __syncthreads();  // planes loaded (ch == 0) / previous channel's CF consumed
-      for (int k = threadIdx.x; k < (TW + 2) * (TH + 2); k += kBlock) {
-        const int ry = k / (TW + 2), rx = k - ry * (TW + 2);
-        const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
-        const int l = (ry + 1) * LW + rx + 1;
-        const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-        float a0 = 0.f, b0 = 0.f, c0 = 0.f, a1 = 0.f, b1 = 0.f, c1 = 0.f, sel = 0.f;
-        if (in) {
-          // the selection must reproduce the forward's e_0 <= e_1 bit for bit:
-          // same moments, same ssim_from_moments expression as loss_stencil_fwd_kernel
-          float m1, m2, m11, m22, m12;
-          moments_lds<LW>(X0 + ch * LP, Tg + ch * LP, l, win, m1, m2, m11, m22, m12);
-          const float v0 = ssim_from_moments(m1, m2, m11, m22, m12);
-          ssim_with_grad(m1, m2, m11, m22, m12, a0, b0, c0);
-          const float e0 = kAlpha * fabsf(X0[ch * LP + l] - Tg[ch * LP + l]) + (1.0f - kAlpha) * clip01_half(v0);
-          moments_lds<LW>(X1 + ch * LP, Tg + ch * LP, l, win, m1, m2, m11, m22, m12);
-          const float v1 = ssim_from_moments(m1, m2, m11, m22, m12);
-          ssim_with_grad(m1, m2, m11, m22, m12, a1, b1, c1);
-          const float e1 = kAlpha * fabsf(X1[ch * LP + l] - Tg[ch * LP + l]) + (1.0f - kAlpha) * clip01_half(v1);
-          sel = (e0 <= e1) ? 1.0f : 0.0f;
-          const float u0 = sel * ku * clip01_half_pass(v0);
-          const float u1 = (1.0f - sel) * ku * clip01_half_pass(v1);
-          a0 *= u0; b0 *= u0; c0 *= u0;
-          a1 *= u1; b1 *= u1; c1 *= u1;
-        }
-        CF[0 * LP + l] = a0; CF[1 * LP + l] = b0; CF[2 * LP + l] = c0;
-        CF[3 * LP + l] = a1; CF[4 * LP + l] = b1; CF[5 * LP + l] = c1;
-        CF[6 * LP + l] = sel;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int k = threadIdx.x + q * kBlock;
-        const int ty = k / TW, tx = k - ty * TW;
-        const int gy = y0 + ty, gx = x0 + tx;
-        if (gy >= d.H || gx >= d.W) continue;
-        const int l = (ty + 2) * LW + tx + 2;
-        const float t = Tg[ch * LP + l], x0v = X0[ch * LP + l], x1v = X1[ch * LP + l];
-        const float sel = CF[6 * LP + l];
-        o0[q][ch] = kE * kAlpha * sel * sgn(x0v - t) + (conv3_lds<LW>(CF + 0 * LP, l, win) +
-                    2.0f * conv3_lds<LW>(CF + 1 * LP, l, win) * x0v + conv3_lds<LW>(CF + 2 * LP, l, win) * t);
-        o1[q][ch] = kE * kAlpha * (1.0f - sel) * sgn(x1v - t) + (conv3_lds<LW>(CF + 3 * LP, l, win) +
-                    2.0f * conv3_lds<LW>(CF + 4 * LP, l, win) * x1v + conv3_lds<LW>(CF + 5 * LP, l, win) * t);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int k = threadIdx.x + q * kBlock;
-      const int ty = k / TW, tx = k - ty * TW;
-      const int gy = y0 + ty, gx = x0 + tx;
-      if (gy >= d.H || gx >= d.W) continue;
-      const size_t pix = (size_t)gy * d.W + gx;
-      st3(dG + g0 + pix * 3, o0[q][0], o0[q][1], o0[q][2]);
-      st3(dG + g1 + pix * 3, o1[q][0], o1[q][1], o1[q][2]);
-    }
-  }
 }
 
 // ------------------------------------------------------------------ fused warp backward
@@ -665,7 +289,8 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
                                                                const float* __restrict__ trans,
                                                                const float* __restrict__ params,
                                                                const float* __restrict__ Hb,
-                                                               const float* __restrict__ dG, LossDims d, float step_x,
+                                                               const float* __restrict__ dG,
+                                                               const float* __restrict__ coef, LossDims d, float step_x,
                                                                float step_y, float* __restrict__ d_depth,
                                                                float* __restrict__ d_trans,
                                                                float* __restrict__ dPp, float* __restrict__ Ovf,
@@ -677,12 +302,14 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
   const size_t img = (size_t)b * HW;
   const size_t sb = ((size_t)s * d.B + b) * HW;
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
+  const float gl = coef[0];  // dL/d loss
   float ddsum[kLossPPT];
 #pragma unroll
   for (int it = 0; it < kLossPPT; ++it) ddsum[it] = 0.0f;
   for (int i = 0; i < d.N; ++i) {
     const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-    const float* hb = Hb + (((size_t)s * d.N + i) * d.B + b) * HW * 4;
+    const float* hb = Hb + (((size_t)s * d.N + i) * d.B + b) * HW * 8;
+    const float kv = coef[1 + s * d.N + i];  // gloss * kV(s, i)
     // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
     float4* ovz = flags[(s * d.N + i) * d.B + b]
                       ? reinterpret_cast<float4*>(Ovf + (((size_t)s * d.N + i) * d.B + b) * HW * 4) : nullptr;
@@ -707,10 +334,10 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
           const f3 a = ld3(sbase + (size_t)i00 * C3), bb = ld3(sbase + (size_t)i01 * C3);
           const f3 cc = ld3(sbase + (size_t)i10 * C3), dd = ld3(sbase + (size_t)i11 * C3);
           const f3 go = ld3(dG + ((((size_t)s * ng + i) * d.B + b) * HW + p) * 3);
-          gx_ = go.x * (wy0 * (cc.x - a.x) + wy1 * (dd.x - bb.x)) + go.y * (wy0 * (cc.y - a.y) + wy1 * (dd.y - bb.y)) +
-                go.z * (wy0 * (cc.z - a.z) + wy1 * (dd.z - bb.z));
-          gy_ = go.x * (wx0 * (bb.x - a.x) + wx1 * (dd.x - cc.x)) + go.y * (wx0 * (bb.y - a.y) + wx1 * (dd.y - cc.y)) +
-                go.z * (wx0 * (bb.z - a.z) + wx1 * (dd.z - cc.z));
+          gx_ = gl * (go.x * (wy0 * (cc.x - a.x) + wy1 * (dd.x - bb.x)) + go.y * (wy0 * (cc.y - a.y) + wy1 * (dd.y - bb.y)) +
+                      go.z * (wy0 * (cc.z - a.z) + wy1 * (dd.z - bb.z)));
+          gy_ = gl * (go.x * (wx0 * (bb.x - a.x) + wx1 * (dd.x - cc.x)) + go.y * (wx0 * (bb.y - a.y) + wx1 * (dd.y - cc.y)) +
+                      go.z * (wx0 * (bb.z - a.z) + wx1 * (dd.z - cc.z)));
         }
         const SplatW sw = splat_weights(g.x, g.y, c, true, g.z);
         const f3 tv = ld3(tgt + (img + p) * 3);
@@ -718,8 +345,11 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
         float dgk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float4 h = *reinterpret_cast<const float4*>(hb + (size_t)idx[k] * 4);
-          dgk[k] = (((h.x * tv.x + h.y * tv.y) + h.z * tv.z) - h.w) * sw.g[k];
+          const float4 ha = *reinterpret_cast<const float4*>(hb + (size_t)idx[k] * 8);
+          const float4 hv = *reinterpret_cast<const float4*>(hb + (size_t)idx[k] * 8 + 4);
+          const float da = ((ha.x * tv.x + ha.y * tv.y) + ha.z * tv.z) - ha.w;
+          const float dv = ((hv.x * tv.x + hv.y * tv.y) + hv.z * tv.z) - hv.w;
+          dgk[k] = (gl * da + kv * dv) * sw.g[k];
         }
         gx_ += -(dgk[0] + dgk[1]) * sw.dx0 + (dgk[2] + dgk[3]) * sw.dx1;
         gy_ += -(dgk[0] + dgk[2]) * sw.dy0 + (dgk[1] + dgk[3]) * sw.dy1;
@@ -746,8 +376,7 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
 // Optional measurement aid for bench.py: when enabled, the two loss entry points bracket
 // each launch with HIP events on the caller's stream.  Off by default (no events, no
 // overhead); process-wide, not thread-safe - a bench facility, not part of the data path.
-enum { ST_SHIFT = 0, ST_WARP_FWD, ST_STENCIL_FWD, ST_REDUCE, ST_FINALIZE, ST_STENCIL_BWD, ST_WARP_BWD, ST_POSE_GRAD,
-       ST_COUNT };
+enum { ST_SHIFT = 0, ST_WARP_FWD, ST_STENCIL, ST_REDUCE, ST_FINALIZE, ST_WARP_BWD, ST_POSE_GRAD, ST_COUNT };
 static bool g_prof_on = false;
 static hipEvent_t g_ev[ST_COUNT][2];
 static bool g_ev_used[ST_COUNT];
@@ -766,7 +395,28 @@ struct StageTimer {
 
 static inline bool dims_ok(const LossDims& d) {
   return d.B > 0 && d.H > 0 && d.W > 0 && d.S > 0 && d.N >= 2 && d.N <= kMaxSrc && d.B <= 65535 && d.S <= 65535 &&
-         (long)d.S * d.N * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 4 ? 3 * d.N : 4);
+         (long)d.S * d.N * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 8 ? 3 * d.N : 8);
+}
+
+// Tuning knob (experiments only): image rows per stencil wave; 0 = the heuristic of stencil_plan.
+static int stencil_rows_override() {
+  static const int v = [] {
+    const char* e = getenv("SFM_STENCIL_ROWS");
+    const int r = e ? atoi(e) : 0;
+    return (r >= 1 && r <= 4096) ? r : 0;
+  }();
+  return v;
+}
+
+struct LossLayout {
+  StencilPlan sp;
+  LossWs w;
+};
+static inline LossLayout loss_layout(const LossDims& d) {
+  LossLayout l;
+  l.sp = stencil_plan(d, stencil_rows_override());
+  l.w = loss_ws(d, l.sp);
+  return l;
 }
 
 }  // namespace sfm
@@ -781,7 +431,7 @@ extern "C" int sfm_pose_grad(const float* pose, long pose_sb, long pose_si, cons
 extern "C" long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N) {
   LossDims d{B, H, W, S, N};
   if (!dims_ok(d)) return SFM_ERR_ARG;
-  return (long long)loss_ws(d).total;
+  return (long long)loss_layout(d).w.total;
 }
 
 extern "C" int sfm_loss_num_partials(int B, int H, int W, int S, int N) {
@@ -796,7 +446,7 @@ extern "C" int sfm_loss_num_partials(int B, int H, int W, int S, int N) {
 extern "C" int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, int N, void* stream_) {
   LossDims d{B, H, W, S, N};
   if (!ws || !dims_ok(d)) return SFM_ERR_ARG;
-  const LossWs w = loss_ws(d);
+  const LossWs w = loss_layout(d).w;
   hipStream_t stream = (hipStream_t)stream_;
   hipError_t e = hipMemsetAsync(ws + w.Ovf, 0, (size_t)S * N * B * H * W * 4 * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
@@ -805,12 +455,14 @@ extern "C" int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, in
 }
 
 extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
-                                const float* params, float* ws, int B, int H, int W, int S, int N, double* partials,
-                                void* stream_) {
+                                const float* params, float* ws, int B, int H, int W, int S, int N,
+                                long long n_elem_global, int need_grad, double* partials, void* stream_) {
   LossDims d{B, H, W, S, N};
-  if (!tgt || !src || !depth || !trans || !params || !ws || !partials || !dims_ok(d)) return SFM_ERR_ARG;
+  if (!tgt || !src || !depth || !trans || !params || !ws || !partials || n_elem_global <= 0 || !dims_ok(d))
+    return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  const LossWs w = loss_ws(d);
+  const LossLayout l = loss_layout(d);
+  const LossWs& w = l.w;
   int2* shift = reinterpret_cast<int2*>(ws + w.shift);
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   { StageTimer t(ST_SHIFT, stream);
@@ -820,18 +472,21 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
   { StageTimer t(ST_WARP_FWD, stream);
   hipLaunchKernelGGL(loss_splat_tile_kernel, dim3(w.stiles_x, w.stiles_y, w.n_img), dim3(kBlock), 0, stream, tgt, src,
                      depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
-                     flags, getenv("SFM_DBG") ? atoi(getenv("SFM_DBG")) : 0); }
-  { StageTimer t(ST_STENCIL_FWD, stream);
-  hipLaunchKernelGGL(loss_stencil_fwd_kernel, dim3(w.tiles_x, w.tiles_y, S * B), dim3(kBlock), 0, stream, tgt, src,
-                     ws + w.G, ws + w.Acc, ws + w.Ovf, flags, d, ws + w.blkp); }
+                     flags); }
+  int rc = sfm_last_error();
+  if (rc) return rc;
+  { StageTimer t(ST_STENCIL, stream);
+  StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, ws + w.Hb, ws + w.dG, ws + w.wavep, d, l.sp,
+                (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global)};
+  rc = launch_loss_stencil(a, need_grad != 0, stream);
+  if (rc) return rc; }
   { StageTimer t(ST_REDUCE, stream);
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(S), dim3(kBlock), 0, stream, ws + w.blkp, B * w.tiles_x * w.tiles_y, N,
-                     partials); }
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 3 * N + 1), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials); }
   return sfm_last_error();
 }
 
-// partials: the (all-reduced) sums of sfm_loss_forward; n_elem_global = B_global*H*W*3.
-// loss_out: one float.  need_grad = 0 stops after the loss.
+// partials: the (all-reduced) sums of sfm_loss_forward; n_elem_global = B_global*H*W*3 (the value
+// given to sfm_loss_forward).  loss_out: one float.  need_grad = 0 stops after the loss.
 extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float* depth, const float* trans,
                                  const float* params, float* ws, int B, int H, int W, int S, int N,
                                  long long n_elem_global, float gloss, int need_grad, const double* partials,
@@ -843,7 +498,7 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
     return SFM_ERR_ARG;
   if (need_grad && (!pose || !K || !d_depth || !d_trans || !d_pose)) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  const LossWs w = loss_ws(d);
+  const LossWs w = loss_layout(d).w;
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   { StageTimer t(ST_FINALIZE, stream);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, gloss,
@@ -853,12 +508,9 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_img * sizeof(int), stream);
     return e != hipSuccess ? (int)e : sfm_last_error();
   }
-  { StageTimer t(ST_STENCIL_BWD, stream);
-  hipLaunchKernelGGL(loss_stencil_bwd_kernel, dim3(w.tiles_x, w.tiles_y, S * B), dim3(kBlock), 0, stream, tgt, src,
-                     ws + w.G, ws + w.Acc, ws + w.Ovf, flags, ws + w.coef, d, ws + w.Hb, ws + w.dG); }
   { StageTimer t(ST_WARP_BWD, stream);
   hipLaunchKernelGGL(loss_warp_bwd_kernel, dim3(w.nblk_bwd, B, S), dim3(kBlock), 0, stream, tgt, src, depth, trans,
-                     params, ws + w.Hb, ws + w.dG, d, sfm_lin_step(W), sfm_lin_step(H), d_depth, d_trans,
+                     params, ws + w.Hb, ws + w.dG, ws + w.coef, d, sfm_lin_step(W), sfm_lin_step(H), d_depth, d_trans,
                      ws + w.dPp, ws + w.Ovf, flags); }
   int rc = sfm_last_error();
   if (rc) return rc;
@@ -888,8 +540,8 @@ extern "C" int sfm_prof_enable(int on) {
 extern "C" int sfm_prof_stages(void) { return ST_COUNT; }
 
 // Adds the elapsed milliseconds of the last step's launches into ms[ST_COUNT]; the
-// caller must have synchronised the stream.  Stage order: tile_shift, warp_fwd, stencil_fwd,
-// reduce, finalize, stencil_bwd, warp_bwd, pose_grad.
+// caller must have synchronised the stream.  Stage order: tile_shift, warp_fwd, stencil,
+// reduce, finalize, warp_bwd, pose_grad.
 extern "C" int sfm_prof_read(float* ms) {
   if (!g_ev_made || !ms) return SFM_ERR_ARG;
   for (int i = 0; i < ST_COUNT; ++i) {

@@ -1,0 +1,105 @@
+// Shared between the translation units of the fused multi-scale loss (loss.hip: host entry
+// points + the two warp kernels; loss_stencil.hip: the streaming L1/SSIM stencil kernel).
+#pragma once
+#include "sfm_device.h"
+#include "sfm_internal.h"
+
+namespace sfm {
+
+constexpr int kMaxSrc = 4;
+constexpr float kAlpha = 0.15f;  // SfMLearner_uni.py:84
+
+struct LossDims {
+  int B, H, W, S, N;
+};
+
+// ---- streaming stencil geometry -------------------------------------------------------
+// One wave = one strip of 64 image columns (the outer two on each side are halo: 60 owned)
+// marching down `rows` image rows (+2 halo rows above and below).  No LDS, no barriers.
+constexpr int kStripOwn = 60;
+constexpr int kWaveTerms = 4;  // per-wave partial sums: splat (A, M, V, -), gather (E, -, -, -)
+
+struct StencilPlan {
+  int strips;   // per image row
+  int rows;     // image rows owned by one wave
+  int chunks;   // per image column
+  int per_img;  // strips * chunks
+  long n_splat, n_gather;  // work items (waves)
+};
+
+static inline StencilPlan stencil_plan(const LossDims& d, int rows_override) {
+  StencilPlan p;
+  p.strips = (d.W + kStripOwn - 1) / kStripOwn;
+  const long imgs = (long)d.S * d.B * (d.N + (d.N >= 2 ? 1 : 0));
+  int rows = 64;  // fewer halo rows per owned row; shrink until the chip has enough waves
+  while (rows > 8 && imgs * p.strips * ((d.H + rows - 1) / rows) < 8192) rows >>= 1;
+  if (rows_override > 0) rows = rows_override;
+  p.rows = rows;
+  p.chunks = (d.H + rows - 1) / rows;
+  p.per_img = p.strips * p.chunks;
+  p.n_splat = (long)d.S * d.N * d.B * p.per_img;
+  p.n_gather = d.N >= 2 ? (long)d.S * d.B * p.per_img : 0;
+  return p;
+}
+
+// ---- workspace map (floats) -------------------------------------------------------------
+//   Acc [S,N,B,H,W,4]   splat accumulators (sum g*rgb, sum g), one 16-byte unit per pixel
+//   Ovf [S,N,B,H,W,4]   overflow side accumulator (all zero between steps)
+//   Hb  [S,N,B,H,W,8]   backward: per destination pixel (hA[3], sum_c hA*Sp, hB[3], sum_c hB*Sp)
+//   G   [S,2,B,H,W,3]   gathered sources 0,1
+//   dG  [S,2,B,H,W,3]   backward: dL/dG_i (gloss = 1)
+//   wavep [n_waves][4]  per-wave partial sums of the stencil kernel
+//   dPp [S,N,B,nblk,12] dL/dP block partials of the backward warp
+constexpr int STW = 64, STH = 16;  // splat: destination tile of one workgroup
+constexpr int kLossPPT = 4;        // pixels per thread in the backward warp kernel
+
+struct LossWs {
+  size_t G, Acc, Ovf, Hb, dG, wavep, dPp, coef, shift, flags, total;
+  int nblk_bwd, stiles_x, stiles_y, n_img;
+};
+
+static inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
+
+static inline LossWs loss_ws(const LossDims& d, const StencilPlan& sp) {
+  LossWs w;
+  const size_t npx = (size_t)d.B * d.H * d.W;
+  const int ng = d.N < 2 ? d.N : 2;
+  w.nblk_bwd = (d.H * d.W + kBlock * kLossPPT - 1) / (kBlock * kLossPPT);
+  w.stiles_x = (d.W + STW - 1) / STW;
+  w.stiles_y = (d.H + STH - 1) / STH;
+  w.n_img = d.S * d.N * d.B;
+  size_t o = 0;
+  w.Acc = o; o += (size_t)d.S * d.N * npx * 4;
+  w.Ovf = o; o += (size_t)d.S * d.N * npx * 4;
+  w.Hb = o;  o += (size_t)d.S * d.N * npx * 8;
+  w.G = o;   o += up4((size_t)d.S * ng * npx * 3);
+  w.dG = o;  o += up4((size_t)d.S * ng * npx * 3);
+  w.wavep = o; o += up4((size_t)(sp.n_splat + sp.n_gather) * kWaveTerms);
+  w.dPp = o; o += up4((size_t)d.S * d.N * d.B * w.nblk_bwd * 12);
+  w.coef = o; o += 64;
+  w.shift = o; o += up4((size_t)w.n_img * w.stiles_x * w.stiles_y * 2);
+  w.flags = o; o += up4((size_t)w.n_img);
+  w.total = o;
+  return w;
+}
+
+struct StencilArgs {
+  const float* tgt;
+  const float* src;
+  const float* G;
+  const float* Acc;
+  const float* Ovf;
+  const int* flags;
+  float* Hb;
+  float* dG;
+  float* wavep;
+  LossDims d;
+  StencilPlan p;
+  float kL1;  // alpha / n_elem_global          (coefficient of the masked L1 term, :149)
+  float kE;   // 2 / n_elem_global              (coefficient of the min-reprojection term, :168)
+};
+
+// loss_stencil.hip
+int launch_loss_stencil(const StencilArgs& a, bool need_grad, hipStream_t stream);
+
+}  // namespace sfm

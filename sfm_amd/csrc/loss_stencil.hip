@@ -1,0 +1,420 @@
+// Streaming L1 + SSIM stencil of the fused loss (SfMLearner_uni.py:137-149, 168; tf_ssim
+// utils.py:548-575), forward sums AND backward seeds in ONE pass over the data.
+//
+// Why one pass is possible: the backward through  mean(m) * clip((1 - mean ssim(Sp, src)) / 2)
+// needs the GLOBAL sums M = sum m and V = sum ssim (utils.py:573-575 takes the mean before the
+// clip).  Everything downstream of this kernel is linear in dL/dSp, so the kernel writes the two
+// parts separately - hA (masked-L1 part, coefficient alpha/n known up front) and hB (SSIM part,
+// to be scaled by kV = (1-alpha) (M/n) (-1/2) [clip passes] / n once the sums are global) - and
+// the backward warp combines them.  The gather side (min-reprojection, :168) has no such
+// dependence: dL/dG is final here.
+//
+// Work decomposition: one WAVE owns a strip of 60 image columns (64 lanes, 2 halo lanes on each
+// side) and marches down `rows` image rows.  Horizontal neighbours come from the adjacent lanes
+// by DPP wave shifts (v_*_dpp wave_shr:1 / wave_shl:1, full VALU rate), vertical neighbours from
+// a 3-row sliding window held in registers; the 3x3 Gaussian window of tf_ssim is separable
+// (w_ij = g_i g_j), so every windowed moment is one horizontal and one vertical 3-tap pass.
+// The chained second stencil of the backward (dSSIM/dx = conv(a) + 2 x conv(b) + y conv(c), the
+// transpose of the window applied to the per-pixel derivative coefficients) runs two rows
+// behind in the same sweep.  No LDS, no barriers, every input element is loaded once per strip
+// (x 64/60) and chunk (x (rows+4)/rows) with fully coalesced 12/16-byte-per-lane loads.
+#include "loss_common.h"
+
+namespace sfm {
+
+namespace {
+
+// tf_ssim window (utils.py:504-519, size 3, sigma 1.5) in separable form w_ij = g_|i| * g_|j|,
+// g = (e1, 1, e1) / (1 + 2 e1), e1 = exp(-1/4.5).  The fp32 values are the pair of neighbouring
+// floats whose 2-D weights sum to exactly 1, as the reference's normalised fp32 window does: a
+// weight sum of 1 + eps biases every variance by eps * mean^2, which tf_ssim's C2 = 9e-4 turns
+// into a systematic ~eps / C2 relative error of the SSIM gradients (6e-8 -> 7e-5).
+constexpr float kG0 = 0.38439732789993286f;
+constexpr float kG1 = 0.30780133605003357f;
+
+__device__ __forceinline__ float lane_left(float v) {  // lane i <- lane i-1 (0 into lane 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_right(float v) {  // lane i <- lane i+1 (0 into lane 63)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float hsum3(float v) { return kG0 * v + kG1 * (lane_left(v) + lane_right(v)); }
+__device__ __forceinline__ float vsum3(float top, float mid, float bot) { return kG0 * mid + kG1 * (top + bot); }
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+
+__device__ __forceinline__ float clip01_half(float v) {  // clip((1 - v)/2, 0, 1), utils.py:575
+  return fminf(fmaxf((1.0f - v) / 2.0f, 0.0f), 1.0f);
+}
+__device__ __forceinline__ float clip01_half_pass(float v) {
+  const float h = (1.0f - v) / 2.0f;
+  return (h >= 0.0f && h <= 1.0f) ? 1.0f : 0.0f;
+}
+__device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
+
+// SSIM value (utils.py:572) from the five windowed raw moments and, if GRAD, its partial
+// derivatives: d value / d (windowed mean of x) = a, / d (windowed mean of x*x) = b,
+// / d (windowed mean of x*y) = c, with x the differentiated image.  One reciprocal per factor.
+template <bool GRAD>
+__device__ __forceinline__ float ssim_point(float m1, float m2, float m11, float m22, float m12, float& a, float& b,
+                                            float& c) {
+  const float mu1_sq = m1 * m1, mu2_sq = m2 * m2, mu12 = m1 * m2;
+  const float s11 = m11 - mu1_sq, s22 = m22 - mu2_sq, s12 = m12 - mu12;
+  const float A1 = 2.0f * mu12 + kSsimC1, A2 = 2.0f * s12 + kSsimC2;
+  const float B1 = mu1_sq + mu2_sq + kSsimC1, B2 = s11 + s22 + kSsimC2;
+  const float iB1 = fast_rcp(B1), iB2 = fast_rcp(B2);
+  const float iB = iB1 * iB2;
+  const float v = (A1 * A2) * iB;
+  if constexpr (GRAD) {
+    c = 2.0f * A1 * iB;                                   // dv / d s12
+    b = -v * iB2;                                         // dv / d s11
+    const float dv_dm1 = (2.0f * m2 * A2) * iB - v * (2.0f * m1) * iB1;
+    a = dv_dm1 - 2.0f * m1 * b - m2 * c;
+  }
+  return v;
+}
+
+struct Item {
+  int img, chunk, strip;
+};
+__device__ __forceinline__ Item split_item(long item, const StencilPlan& p) {
+  Item it;
+  it.strip = (int)(item % p.strips);
+  const long r = item / p.strips;
+  it.chunk = (int)(r % p.chunks);
+  it.img = (int)(r / p.chunks);
+  return it;
+}
+
+__device__ __forceinline__ float rows_in(int q, int H) {  // in-bounds taps of a 3-tap window at q
+  return (float)(min(q + 1, H - 1) - max(q - 1, 0) + 1);
+}
+
+// ------------------------------------------------------------------ splat side
+// x = Sp_i = Acc.rgb / (Acc.w + 1e-10) (utils.py:463,470), y = src_i.  Sums A = sum m |x - y|,
+// M = sum m, V = sum ssim(x, y) with m = avgpool3x3_SAME(1 - [x == 0]) (utils.py:478-479).
+template <bool GRAD>
+__device__ __forceinline__ void splat_item(const StencilArgs& a, long item, float* __restrict__ wavep_out) {
+  const LossDims d = a.d;
+  const Item it = split_item(item, a.p);
+  const int lane = threadIdx.x & 63;
+  const int b = it.img % d.B, i = (it.img / d.B) % d.N;
+  const int HW = d.H * d.W, C3 = 3 * d.N;
+  const int gx = it.strip * kStripOwn - 2 + lane;
+  const bool col_in = gx >= 0 && gx < d.W;
+  const bool own_col = lane >= 2 && lane < 62 && gx < d.W;
+  const int y0 = it.chunk * a.p.rows, y1 = min(y0 + a.p.rows, d.H);
+  const float* __restrict__ acc = a.Acc + (size_t)it.img * HW * 4;
+  const float* __restrict__ ovf = a.flags[it.img] ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;  // wave-uniform
+  const float* __restrict__ sp = a.src + (size_t)b * HW * C3 + 3 * i;
+  float* __restrict__ hb = a.Hb + (size_t)it.img * HW * 8;
+  const float nx = (float)(min(gx + 1, d.W - 1) - max(gx - 1, 0) + 1);
+  constexpr int HAL = GRAD ? 2 : 1;
+
+  float Hm[2][3][5], Nz[2][3];   // horizontal moment sums / non-zero counts of rows r-2, r-1
+  float Ch[2][3][3];             // horizontal sums of (a, b, c) of rows r-3, r-2
+  float X[2][3], Y[2][3], Iv[2]; // centre values of rows r-2, r-1 and 1 / (D + 1e-10)
+  float Mp[3];                   // mask of row r-2
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    Iv[k] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      Nz[k][ch] = X[k][ch] = Y[k][ch] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) Hm[k][ch][m] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) Ch[k][ch][m] = 0.f;
+    }
+  }
+  Mp[0] = Mp[1] = Mp[2] = 0.f;
+  float sA = 0.f, sM = 0.f, sV = 0.f;
+
+  // software prefetch of the next row's raw values
+  float4 na = make_float4(0.f, 0.f, 0.f, 0.f);
+  f3 ns{0.f, 0.f, 0.f};
+  auto fetch = [&](int r) {
+    na = make_float4(0.f, 0.f, 0.f, 0.f);
+    ns = f3{0.f, 0.f, 0.f};
+    if (r >= 0 && r < d.H && col_in) {
+      const size_t p = (size_t)r * d.W + gx;
+      na = *reinterpret_cast<const float4*>(acc + p * 4);
+      if (ovf) {
+        const float4 o = *reinterpret_cast<const float4*>(ovf + p * 4);
+        na.x += o.x; na.y += o.y; na.z += o.z; na.w += o.w;
+      }
+      ns = ld3(sp + p * C3);
+    }
+  };
+  fetch(y0 - HAL);
+  for (int r = y0 - HAL; r <= y1 - 1 + HAL; ++r) {
+    const float4 ca = na;
+    const f3 cs = ns;
+    if (r + 1 <= y1 - 1 + HAL) fetch(r + 1);
+    const bool row_in = r >= 0 && r < d.H;  // wave-uniform
+    // ---- row r: values, horizontal sums
+    float x[3], y[3], hc[3][5], nzc[3], inv = 0.f;
+    if (row_in) {
+      const float den = ca.w + 1e-10f;
+      inv = col_in ? 1.0f / den : 0.f;
+      x[0] = ca.x / den; x[1] = ca.y / den; x[2] = ca.z / den;  // 0 outside the image (ca = 0)
+      y[0] = cs.x; y[1] = cs.y; y[2] = cs.z;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        hc[ch][0] = hsum3(x[ch]);
+        hc[ch][1] = hsum3(y[ch]);
+        hc[ch][2] = hsum3(x[ch] * x[ch]);
+        hc[ch][3] = hsum3(y[ch] * y[ch]);
+        hc[ch][4] = hsum3(x[ch] * y[ch]);
+        const float nz = (x[ch] == 0.0f) ? 0.0f : 1.0f;
+        nzc[ch] = nz + (lane_left(nz) + lane_right(nz));
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        x[ch] = y[ch] = nzc[ch] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) hc[ch][m] = 0.f;
+      }
+    }
+    // ---- row q = r - 1: windowed moments -> SSIM value, derivative coefficients, mask, sums
+    const int q = r - 1;
+    float chc[3][3], mq[3];
+    if (r - (y0 - HAL) >= 2) {
+      const bool q_in = q >= 0 && q < d.H;
+      const bool pix_in = q_in && col_in;
+      const bool own = own_col && q >= y0 && q < y1;
+      const float cnt = rows_in(q, d.H) * nx;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float ca_ = 0.f, cb_ = 0.f, cc_ = 0.f;
+        const float v = ssim_point<GRAD>(vsum3(Hm[0][ch][0], Hm[1][ch][0], hc[ch][0]), vsum3(Hm[0][ch][1], Hm[1][ch][1], hc[ch][1]),
+                                         vsum3(Hm[0][ch][2], Hm[1][ch][2], hc[ch][2]), vsum3(Hm[0][ch][3], Hm[1][ch][3], hc[ch][3]),
+                                         vsum3(Hm[0][ch][4], Hm[1][ch][4], hc[ch][4]), ca_, cb_, cc_);
+        const float m = ((Nz[0][ch] + Nz[1][ch]) + nzc[ch]) / cnt;
+        mq[ch] = m;
+        if (own) {
+          sV += v;
+          sA += m * fabsf(X[1][ch] - Y[1][ch]);
+          sM += m;
+        }
+        if constexpr (GRAD) {
+          chc[ch][0] = hsum3(pix_in ? ca_ : 0.f);
+          chc[ch][1] = hsum3(pix_in ? cb_ : 0.f);
+          chc[ch][2] = hsum3(pix_in ? cc_ : 0.f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        mq[ch] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) chc[ch][m] = 0.f;
+      }
+    }
+    // ---- row p = r - 2: backward seeds
+    if constexpr (GRAD) {
+      const int p = r - 2;
+      if (own_col && p >= y0 && p < y1) {
+        float hA[3], hB[3], wA = 0.f, wB = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float xv = X[0][ch], yv = Y[0][ch];
+          const float rr = vsum3(Ch[0][ch][0], Ch[1][ch][0], chc[ch][0]) +
+                           2.0f * vsum3(Ch[0][ch][1], Ch[1][ch][1], chc[ch][1]) * xv +
+                           vsum3(Ch[0][ch][2], Ch[1][ch][2], chc[ch][2]) * yv;
+          hA[ch] = (a.kL1 * Mp[ch] * sgn(xv - yv)) * Iv[0];
+          hB[ch] = rr * Iv[0];
+          wA += hA[ch] * xv;
+          wB += hB[ch] * xv;
+        }
+        float4* o = reinterpret_cast<float4*>(hb + ((size_t)p * d.W + gx) * 8);
+        o[0] = make_float4(hA[0], hA[1], hA[2], wA);
+        o[1] = make_float4(hB[0], hB[1], hB[2], wB);
+      }
+    }
+    // ---- slide the windows
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+      for (int m = 0; m < 5; ++m) { Hm[0][ch][m] = Hm[1][ch][m]; Hm[1][ch][m] = hc[ch][m]; }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { Ch[0][ch][m] = Ch[1][ch][m]; Ch[1][ch][m] = chc[ch][m]; }
+      Nz[0][ch] = Nz[1][ch]; Nz[1][ch] = nzc[ch];
+      X[0][ch] = X[1][ch]; X[1][ch] = x[ch];
+      Y[0][ch] = Y[1][ch]; Y[1][ch] = y[ch];
+      Mp[ch] = mq[ch];
+    }
+    Iv[0] = Iv[1]; Iv[1] = inv;
+  }
+  sA = wave_sum(sA); sM = wave_sum(sM); sV = wave_sum(sV);
+  if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sA, sM, sV, 0.f);
+}
+
+// ------------------------------------------------------------------ gather side
+// e_i = alpha |G_i - tgt| + (1 - alpha) clip((1 - ssim(G_i, tgt)) / 2, 0, 1)  (:137,142), E = sum min(e_0, e_1)
+// (:168).  dG_i = kE [ alpha sel_i sgn(G_i - tgt) + (1 - alpha)(-1/2) (ssim backward of the selected side) ].
+template <bool GRAD>
+__device__ __forceinline__ void gather_item(const StencilArgs& a, long item, float* __restrict__ wavep_out) {
+  const LossDims d = a.d;
+  const Item it = split_item(item, a.p);
+  const int lane = threadIdx.x & 63;
+  const int s = it.img / d.B, b = it.img - s * d.B;
+  const int HW = d.H * d.W;
+  const int gx = it.strip * kStripOwn - 2 + lane;
+  const bool col_in = gx >= 0 && gx < d.W;
+  const bool own_col = lane >= 2 && lane < 62 && gx < d.W;
+  const int y0 = it.chunk * a.p.rows, y1 = min(y0 + a.p.rows, d.H);
+  const size_t gpix = (size_t)d.B * HW;
+  const size_t o0 = (((size_t)s * 2 + 0) * gpix + (size_t)b * HW) * 3;
+  const size_t o1 = (((size_t)s * 2 + 1) * gpix + (size_t)b * HW) * 3;
+  const float* __restrict__ g0p = a.G + o0;
+  const float* __restrict__ g1p = a.G + o1;
+  const float* __restrict__ tp = a.tgt + (size_t)b * HW * 3;
+  constexpr int HAL = GRAD ? 2 : 1;
+  const float ku = a.kE * (1.0f - kAlpha) * (-0.5f);
+  const float kl = a.kE * kAlpha;
+
+  // moment order per channel: t, tt, x0, x0x0, x0t, x1, x1x1, x1t
+  float Hm[2][3][8];
+  float Ch[2][3][6];                      // (a0, b0, c0, a1, b1, c1), already scaled by the selection
+  float X0[2][3], X1[2][3], T[2][3];      // centre values of rows r-2, r-1
+  float Sel[3];                           // selection of row r-2
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      X0[k][ch] = X1[k][ch] = T[k][ch] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) Hm[k][ch][m] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) Ch[k][ch][m] = 0.f;
+    }
+  Sel[0] = Sel[1] = Sel[2] = 0.f;
+  float sE = 0.f;
+
+  f3 n0{0.f, 0.f, 0.f}, n1{0.f, 0.f, 0.f}, nt{0.f, 0.f, 0.f};
+  auto fetch = [&](int r) {
+    n0 = n1 = nt = f3{0.f, 0.f, 0.f};
+    if (r >= 0 && r < d.H && col_in) {
+      const size_t p = ((size_t)r * d.W + gx) * 3;
+      n0 = ld3(g0p + p);
+      n1 = ld3(g1p + p);
+      nt = ld3(tp + p);
+    }
+  };
+  fetch(y0 - HAL);
+  for (int r = y0 - HAL; r <= y1 - 1 + HAL; ++r) {
+    const float x0[3] = {n0.x, n0.y, n0.z}, x1[3] = {n1.x, n1.y, n1.z}, t[3] = {nt.x, nt.y, nt.z};
+    if (r + 1 <= y1 - 1 + HAL) fetch(r + 1);
+    const bool row_in = r >= 0 && r < d.H;
+    float hc[3][8];
+    if (row_in) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        hc[ch][0] = hsum3(t[ch]);
+        hc[ch][1] = hsum3(t[ch] * t[ch]);
+        hc[ch][2] = hsum3(x0[ch]);
+        hc[ch][3] = hsum3(x0[ch] * x0[ch]);
+        hc[ch][4] = hsum3(x0[ch] * t[ch]);
+        hc[ch][5] = hsum3(x1[ch]);
+        hc[ch][6] = hsum3(x1[ch] * x1[ch]);
+        hc[ch][7] = hsum3(x1[ch] * t[ch]);
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) hc[ch][m] = 0.f;
+    }
+    const int q = r - 1;
+    float chc[3][6], selq[3];
+    if (r - (y0 - HAL) >= 2) {
+      const bool pix_in = q >= 0 && q < d.H && col_in;
+      const bool own = own_col && q >= y0 && q < y1;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float mm[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mm[m] = vsum3(Hm[0][ch][m], Hm[1][ch][m], hc[ch][m]);
+        float a0 = 0.f, b0 = 0.f, c0 = 0.f, a1 = 0.f, b1 = 0.f, c1 = 0.f;
+        const float v0 = ssim_point<GRAD>(mm[2], mm[0], mm[3], mm[1], mm[4], a0, b0, c0);
+        const float v1 = ssim_point<GRAD>(mm[5], mm[0], mm[6], mm[1], mm[7], a1, b1, c1);
+        const float e0 = kAlpha * fabsf(X0[1][ch] - T[1][ch]) + (1.0f - kAlpha) * clip01_half(v0);
+        const float e1 = kAlpha * fabsf(X1[1][ch] - T[1][ch]) + (1.0f - kAlpha) * clip01_half(v1);
+        const bool first = e0 <= e1;  // tf.minimum ties -> either (equal values)
+        selq[ch] = first ? 1.0f : 0.0f;
+        if (own) sE += first ? e0 : e1;
+        if constexpr (GRAD) {
+          const float u0 = (pix_in && first) ? ku * clip01_half_pass(v0) : 0.f;
+          const float u1 = (pix_in && !first) ? ku * clip01_half_pass(v1) : 0.f;
+          chc[ch][0] = hsum3(a0 * u0); chc[ch][1] = hsum3(b0 * u0); chc[ch][2] = hsum3(c0 * u0);
+          chc[ch][3] = hsum3(a1 * u1); chc[ch][4] = hsum3(b1 * u1); chc[ch][5] = hsum3(c1 * u1);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        selq[ch] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) chc[ch][m] = 0.f;
+      }
+    }
+    if constexpr (GRAD) {
+      const int p = r - 2;
+      if (own_col && p >= y0 && p < y1) {
+        float d0[3], d1[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float tv = T[0][ch], xa = X0[0][ch], xb = X1[0][ch];
+          d0[ch] = kl * Sel[ch] * sgn(xa - tv) +
+                   (vsum3(Ch[0][ch][0], Ch[1][ch][0], chc[ch][0]) + 2.0f * vsum3(Ch[0][ch][1], Ch[1][ch][1], chc[ch][1]) * xa +
+                    vsum3(Ch[0][ch][2], Ch[1][ch][2], chc[ch][2]) * tv);
+          d1[ch] = kl * (1.0f - Sel[ch]) * sgn(xb - tv) +
+                   (vsum3(Ch[0][ch][3], Ch[1][ch][3], chc[ch][3]) + 2.0f * vsum3(Ch[0][ch][4], Ch[1][ch][4], chc[ch][4]) * xb +
+                    vsum3(Ch[0][ch][5], Ch[1][ch][5], chc[ch][5]) * tv);
+        }
+        const size_t pp = ((size_t)p * d.W + gx) * 3;
+        st3(a.dG + o0 + pp, d0[0], d0[1], d0[2]);
+        st3(a.dG + o1 + pp, d1[0], d1[1], d1[2]);
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { Hm[0][ch][m] = Hm[1][ch][m]; Hm[1][ch][m] = hc[ch][m]; }
+#pragma unroll
+      for (int m = 0; m < 6; ++m) { Ch[0][ch][m] = Ch[1][ch][m]; Ch[1][ch][m] = chc[ch][m]; }
+      X0[0][ch] = X0[1][ch]; X0[1][ch] = x0[ch];
+      X1[0][ch] = X1[1][ch]; X1[1][ch] = x1[ch];
+      T[0][ch] = T[1][ch]; T[1][ch] = t[ch];
+      Sel[ch] = selq[ch];
+    }
+  }
+  sE = wave_sum(sE);
+  if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sE, 0.f, 0.f, 0.f);
+}
+
+// grid: ceil((n_splat + n_gather) / 4) blocks of 4 independent waves.  Gather items first: they
+// are the heavier ones (two SSIMs per channel), so the tail of the launch is made of light waves.
+template <bool GRAD>
+__global__ __launch_bounds__(kBlock) void loss_stencil_kernel(StencilArgs a) {
+  const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (w < a.p.n_gather)
+    gather_item<GRAD>(a, w, a.wavep + (a.p.n_splat + w) * kWaveTerms);
+  else if (w < a.p.n_gather + a.p.n_splat)
+    splat_item<GRAD>(a, w - a.p.n_gather, a.wavep + (w - a.p.n_gather) * kWaveTerms);
+}
+
+}  // namespace
+
+int launch_loss_stencil(const StencilArgs& a, bool need_grad, hipStream_t stream) {
+  const long n = a.p.n_splat + a.p.n_gather;
+  const dim3 grid((unsigned)((n + kBlock / 64 - 1) / (kBlock / 64)));
+  if (need_grad)
+    hipLaunchKernelGGL(loss_stencil_kernel<true>, grid, dim3(kBlock), 0, stream, a);
+  else
+    hipLaunchKernelGGL(loss_stencil_kernel<false>, grid, dim3(kBlock), 0, stream, a);
+  return sfm_last_error();
+}
+
+}  // namespace sfm

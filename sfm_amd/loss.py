@@ -4,7 +4,7 @@
 
     fused=True   one pass of the fused HIP pipeline (sfm_loss_forward / sfm_loss_backward,
                  csrc/loss.hip): geometry evaluated once per (pixel, source), both warps,
-                 L1 + SSIM, masks, min-reprojection and every gradient in 8 launches.
+                 L1 + SSIM, masks, min-reprojection and every gradient in 8 launches (7 kernels + pose set-up).
     fused=False  the reference's op decomposition, each op a stand-alone HIP operator of
                  ``sfm_amd.utils`` glued by torch device ops and torch autograd.
 
@@ -50,13 +50,15 @@ class LossEngine:
         flags = self.ws[-((S * N * B + 3) // 4 * 4):].view(torch.int32)[:S * N * B]
         return int((flags != 0).sum()), float(ovf.abs().max())
 
-    def forward_partials(self, tgt, src, K, depth, pose, trans) -> Tensor:
+    def forward_partials(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool = True) -> Tensor:
+        """First half: both warps, the L1/SSIM stencil and the local partial sums.  ``n_elem_global`` =
+        B_global*H*W*3 (the reduce_mean denominators are global under data parallelism)."""
         B, H, W, S, N = self.dims
         partials = torch.empty(self.n_partials, dtype=torch.float64, device=self.device)
         st = stream_of(tgt)
         call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
         call("sfm_loss_forward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W, S,
-             N, ptr(partials), st)
+             N, int(n_elem_global), int(need_grad), ptr(partials), st)
         return partials
 
     def backward(self, tgt, src, K, depth, pose, trans, partials, n_elem_global: int, gloss: float = 1.0,
@@ -115,10 +117,10 @@ class _FusedPixelLoss(torch.autograd.Function):
         N = pose.shape[1]
         with torch.cuda.device(tgt.device):
             eng = get_engine(B, H, W, S, N, tgt.device)
-            partials = eng.forward_partials(tgt, src, K, depth, pose, trans)
+            need = any(ctx.needs_input_grad[:3])
+            partials = eng.forward_partials(tgt, src, K, depth, pose, trans, global_b * H * W * 3, need)
             if global_b != B or process_group is not None:
                 partials = allreduce_partials(partials, process_group)
-            need = any(ctx.needs_input_grad[:3])
             loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, pose, trans, partials,
                                                           global_b * H * W * 3, 1.0, need)
         if need:

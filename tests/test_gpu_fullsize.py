@@ -2,9 +2,11 @@
 properties of the HIP path instead (the oracle comparisons at small sizes are in
 test_gpu_warp.py / test_gpu_loss.py / test_gpu_golden.py).
 
-  * two independent HIP implementations agree: the fused pipeline (csrc/loss.hip) and the
-    reference's op-by-op decomposition (stand-alone operators of csrc/warp.hip + ssim.hip glued
-    by torch autograd) give the same loss and gradients;
+  * two independent HIP implementations agree: the fused pipeline (csrc/loss.hip, loss_stencil.hip:
+    separable sliding-window SSIM) and the reference's op-by-op decomposition (stand-alone operators
+    of csrc/warp.hip + ssim.hip - direct 9-tap SSIM - glued by torch autograd) give the same loss and
+    gradients, except at the pixels whose min-reprojection selection is numerically undecided
+    (helpers.min_select_ambiguous);
   * the data-parallel sums are additive over the batch: partials(B) == partials(B/2) + partials(B/2)
     - the "checksum of checksums" behind the sharding of SURVEY.md section 8e;
   * both warps are linear in the image; a constant image splats to itself wherever anything lands.
@@ -15,7 +17,7 @@ import torch
 import sfm_amd
 from sfm_amd import synth
 from sfm_amd.loss import LossEngine
-from helpers import TOL_GRAD, TOL_OUT, grad_close, rel_err
+from helpers import TOL_GRAD, TOL_OUT, grad_close, min_select_ambiguous, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -42,11 +44,17 @@ def test_fused_equals_unfused_at_full_size(dev, label, B, H, W, S, N, city):
     lf, df, pf, tf_ = _run(inp, dev, True)
     lu, du, pu, tu = _run(inp, dev, False)
     assert rel_err(lf, lu) <= TOL_OUT
-    assert rel_err(pf.grad, pu.grad) <= TOL_GRAD
+    # d_pose sums every pixel, the ambiguous ones included (each flipped selection moves ~9 per-pixel
+    # gradients by ~1e-2 of their maximum): 3e-4 at these sizes, 1e-4 in the oracle tests at small sizes
+    assert rel_err(pf.grad, pu.grad) <= 3 * TOL_GRAD
+    g = synth.to_device(inp, dev)
     for s in range(S):
-        ok, msg = grad_close(df[s].grad, du[s].grad)
+        with torch.no_grad():
+            amb = min_select_ambiguous(g["tgt"], g["src"], g["K"], g["depth"][s].squeeze(3).contiguous(), g["pose"],
+                                       g["trans"][s])
+        ok, msg = grad_close(df[s].grad, du[s].grad, exclude=amb)
         assert ok, f"d_depth scale {s}: {msg}"
-        ok, msg = grad_close(tf_[s].grad, tu[s].grad)
+        ok, msg = grad_close(tf_[s].grad, tu[s].grad, exclude=amb)
         assert ok, f"d_trans scale {s}: {msg}"
     torch.cuda.empty_cache()
 
@@ -61,7 +69,8 @@ def test_partials_are_additive_over_the_batch(dev, label, B, H, W, S, N, city):
         eng = LossEngine(hi - lo, H, W, S, N, dev)
         return eng.forward_partials(inp["tgt"][lo:hi].contiguous(), inp["src"][lo:hi].contiguous(),
                                     inp["K"][lo:hi].contiguous(), depth[:, lo:hi].contiguous(),
-                                    inp["pose"][lo:hi].contiguous(), trans[:, lo:hi].contiguous()).clone()
+                                    inp["pose"][lo:hi].contiguous(), trans[:, lo:hi].contiguous(),
+                                    B * H * W * 3, False).clone()
 
     whole = part(0, B)
     halves = part(0, B // 2) + part(B // 2, B)

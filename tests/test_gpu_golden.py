@@ -63,7 +63,8 @@ def test_golden_partials_of_the_fused_forward(dev):
     depth = torch.stack([_t(g[f"depth{s}"], dev).squeeze(3) for s in range(S)], 0).contiguous()
     trans = torch.stack([_t(g[f"trans{s}"], dev) for s in range(S)], 0).contiguous()
     eng = LossEngine(B, H, W, S, N, dev)
-    part = eng.forward_partials(_t(g["tgt"], dev), _t(g["src"], dev), _t(g["K"], dev), depth, _t(g["pose"], dev), trans)
+    part = eng.forward_partials(_t(g["tgt"], dev), _t(g["src"], dev), _t(g["K"], dev), depth, _t(g["pose"], dev), trans,
+                                B * H * W * 3, False)
     assert rel_err(part, _t(g["partials"], dev)) <= TOL_OUT
 
 

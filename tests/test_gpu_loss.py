@@ -7,7 +7,7 @@ import torch
 import sfm_amd
 from sfm_amd import synth
 from oracle import ref_graph as R
-from helpers import TOL_GRAD, TOL_OUT, rel_err
+from helpers import TOL_GRAD, TOL_OUT, grad_close, min_select_ambiguous, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -47,9 +47,22 @@ def test_multi_scale_loss(dev, B, H, W, S, N, ps, full, fused):
     lg, dg, pg, tg = _gpu(inp, dev, fused)
     assert rel_err(lg, lo) <= TOL_OUT
     assert rel_err(pg.grad, po.grad) <= TOL_GRAD
+    g = synth.to_device(inp, dev)
     for s in range(S):
-        assert rel_err(dg[s].grad, do[s].grad) <= TOL_GRAD, f"d_depth scale {s}"
-        assert rel_err(tg[s].grad, to[s].grad) <= TOL_GRAD, f"d_trans scale {s}"
+        # per-pixel gradients: strict max-norm outside the 3x3 neighbourhoods of the pixels whose
+        # min-reprojection selection is below fp32 resolution (helpers.min_select_ambiguous)
+        with torch.no_grad():
+            depth_full = sfm_amd.loss.resize_bilinear(g["depth"][s], H, W).squeeze(3).contiguous()
+            trans_full = sfm_amd.loss.resize_bilinear(g["trans"][s], H, W).contiguous()
+            amb = min_select_ambiguous(g["tgt"], g["src"], g["K"], depth_full, g["pose"], trans_full)
+        if not full:  # gradients live at the pyramid resolution: any ambiguous pixel may touch any coarse cell
+            amb = None if not bool(amb.any()) else "skip"
+        for name, a, b in (("d_depth", dg[s].grad, do[s].grad), ("d_trans", tg[s].grad, to[s].grad)):
+            if amb is None or isinstance(amb, str):
+                ok, msg = grad_close(a, b, max_outlier_frac=0.0 if amb is None else 2e-3)
+            else:
+                ok, msg = grad_close(a, b, max_outlier_frac=0.0, exclude=amb)
+            assert ok, f"{name} scale {s}: {msg}"
 
 
 def test_loss_with_smoothness_terms(dev):
