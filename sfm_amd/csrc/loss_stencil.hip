@@ -18,6 +18,10 @@
 // transpose of the window applied to the per-pixel derivative coefficients) runs two rows
 // behind in the same sweep.  No LDS, no barriers, every input element is loaded once per strip
 // (x 64/60) and chunk (x (rows+4)/rows) with fully coalesced 12/16-byte-per-lane loads.
+//
+// This file is compiled WITH fp contraction (FMA) and uses v_rcp_f32 for the SSIM quotients and
+// the splat normalisation: nothing here feeds an integer pixel index, the tolerance is the
+// loss's 1e-5 / the gradients' 1e-4, and the kernel is VALU-issue bound.
 #include "loss_common.h"
 
 namespace sfm {
@@ -154,9 +158,8 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
     // ---- row r: values, horizontal sums
     float x[3], y[3], hc[3][5], nzc[3], inv = 0.f;
     if (row_in) {
-      const float den = ca.w + 1e-10f;
-      inv = col_in ? 1.0f / den : 0.f;
-      x[0] = ca.x / den; x[1] = ca.y / den; x[2] = ca.z / den;  // 0 outside the image (ca = 0)
+      inv = col_in ? fast_rcp(ca.w + 1e-10f) : 0.f;
+      x[0] = ca.x * inv; x[1] = ca.y * inv; x[2] = ca.z * inv;  // 0 outside the image (ca = 0)
       y[0] = cs.x; y[1] = cs.y; y[2] = cs.z;
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
@@ -183,14 +186,14 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
       const bool q_in = q >= 0 && q < d.H;
       const bool pix_in = q_in && col_in;
       const bool own = own_col && q >= y0 && q < y1;
-      const float cnt = rows_in(q, d.H) * nx;
+      const float rcnt = 1.0f / (rows_in(q, d.H) * nx);  // k * fl(1/k) == 1 exactly for k = 4, 6, 9
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         float ca_ = 0.f, cb_ = 0.f, cc_ = 0.f;
         const float v = ssim_point<GRAD>(vsum3(Hm[0][ch][0], Hm[1][ch][0], hc[ch][0]), vsum3(Hm[0][ch][1], Hm[1][ch][1], hc[ch][1]),
                                          vsum3(Hm[0][ch][2], Hm[1][ch][2], hc[ch][2]), vsum3(Hm[0][ch][3], Hm[1][ch][3], hc[ch][3]),
                                          vsum3(Hm[0][ch][4], Hm[1][ch][4], hc[ch][4]), ca_, cb_, cc_);
-        const float m = ((Nz[0][ch] + Nz[1][ch]) + nzc[ch]) / cnt;
+        const float m = ((Nz[0][ch] + Nz[1][ch]) + nzc[ch]) * rcnt;
         mq[ch] = m;
         if (own) {
           sV += v;
@@ -394,26 +397,31 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
   if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sE, 0.f, 0.f, 0.f);
 }
 
-// grid: ceil((n_splat + n_gather) / 4) blocks of 4 independent waves.  Gather items first: they
-// are the heavier ones (two SSIMs per channel), so the tail of the launch is made of light waves.
+// One wave per work item, 4 independent waves per block.  Two kernels because the register
+// budgets differ (the gather side carries two SSIMs per channel).
 template <bool GRAD>
-__global__ __launch_bounds__(kBlock) void loss_stencil_kernel(StencilArgs a) {
+__global__ __launch_bounds__(kBlock) void loss_stencil_gather_kernel(StencilArgs a) {
   const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (w < a.p.n_gather)
-    gather_item<GRAD>(a, w, a.wavep + (a.p.n_splat + w) * kWaveTerms);
-  else if (w < a.p.n_gather + a.p.n_splat)
-    splat_item<GRAD>(a, w - a.p.n_gather, a.wavep + (w - a.p.n_gather) * kWaveTerms);
+  if (w < a.p.n_gather) gather_item<GRAD>(a, w, a.wavep + (a.p.n_splat + w) * kWaveTerms);
+}
+template <bool GRAD>
+__global__ __launch_bounds__(kBlock) void loss_stencil_splat_kernel(StencilArgs a) {
+  const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (w < a.p.n_splat) splat_item<GRAD>(a, w, a.wavep + w * kWaveTerms);
 }
 
 }  // namespace
 
 int launch_loss_stencil(const StencilArgs& a, bool need_grad, hipStream_t stream) {
-  const long n = a.p.n_splat + a.p.n_gather;
-  const dim3 grid((unsigned)((n + kBlock / 64 - 1) / (kBlock / 64)));
-  if (need_grad)
-    hipLaunchKernelGGL(loss_stencil_kernel<true>, grid, dim3(kBlock), 0, stream, a);
-  else
-    hipLaunchKernelGGL(loss_stencil_kernel<false>, grid, dim3(kBlock), 0, stream, a);
+  constexpr int WPB = kBlock / 64;
+  const dim3 gs((unsigned)((a.p.n_splat + WPB - 1) / WPB)), gg((unsigned)((a.p.n_gather + WPB - 1) / WPB));
+  if (need_grad) {
+    if (a.p.n_gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<true>, gg, dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(loss_stencil_splat_kernel<true>, gs, dim3(kBlock), 0, stream, a);
+  } else {
+    if (a.p.n_gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<false>, gg, dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(loss_stencil_splat_kernel<false>, gs, dim3(kBlock), 0, stream, a);
+  }
   return sfm_last_error();
 }
 
