@@ -23,6 +23,7 @@
 // the splat normalisation: nothing here feeds an integer pixel index, the tolerance is the
 // loss's 1e-5 / the gradients' 1e-4, and the kernel is VALU-issue bound.
 #include "loss_common.h"
+#include <type_traits>
 
 namespace sfm {
 
@@ -55,16 +56,16 @@ __device__ __forceinline__ float clip01_half_pass(float v) {
 }
 __device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
 
-// SSIM value (utils.py:572) from the five windowed raw moments and, if GRAD, its partial
-// derivatives: d value / d (windowed mean of x) = a, / d (windowed mean of x*x) = b,
-// / d (windowed mean of x*y) = c, with x the differentiated image.  One reciprocal per factor.
+// SSIM value (utils.py:572) from the windowed raw moments m1 = E[x], m2 = E[y], mss = E[x*x + y*y]
+// (the denominator only needs sigma_x^2 + sigma_y^2, so the two squares share one filter) and
+// m12 = E[x*y]; if GRAD also its partial derivatives with respect to E[x] (a), E[x*x] (b) and
+// E[x*y] (c), x being the differentiated image.  One reciprocal per factor of the denominator.
 template <bool GRAD>
-__device__ __forceinline__ float ssim_point(float m1, float m2, float m11, float m22, float m12, float& a, float& b,
-                                            float& c) {
+__device__ __forceinline__ float ssim_point(float m1, float m2, float mss, float m12, float& a, float& b, float& c) {
   const float mu1_sq = m1 * m1, mu2_sq = m2 * m2, mu12 = m1 * m2;
-  const float s11 = m11 - mu1_sq, s22 = m22 - mu2_sq, s12 = m12 - mu12;
-  const float A1 = 2.0f * mu12 + kSsimC1, A2 = 2.0f * s12 + kSsimC2;
-  const float B1 = mu1_sq + mu2_sq + kSsimC1, B2 = s11 + s22 + kSsimC2;
+  const float musum = mu1_sq + mu2_sq;
+  const float A1 = 2.0f * mu12 + kSsimC1, A2 = 2.0f * (m12 - mu12) + kSsimC2;
+  const float B1 = musum + kSsimC1, B2 = (mss - musum) + kSsimC2;
   const float iB1 = fast_rcp(B1), iB2 = fast_rcp(B2);
   const float iB = iB1 * iB2;
   const float v = (A1 * A2) * iB;
@@ -76,6 +77,9 @@ __device__ __forceinline__ float ssim_point(float m1, float m2, float m11, float
   }
   return v;
 }
+
+template <int V>
+using IC = std::integral_constant<int, V>;
 
 struct Item {
   int img, chunk, strip;
@@ -96,6 +100,9 @@ __device__ __forceinline__ float rows_in(int q, int H) {  // in-bounds taps of a
 // ------------------------------------------------------------------ splat side
 // x = Sp_i = Acc.rgb / (Acc.w + 1e-10) (utils.py:463,470), y = src_i.  Sums A = sum m |x - y|,
 // M = sum m, V = sum ssim(x, y) with m = avgpool3x3_SAME(1 - [x == 0]) (utils.py:478-479).
+//
+// Register windows are 3-slot rings indexed by (row mod 3); the row loop is unrolled by 3 with the
+// phase as a compile-time constant, so sliding a window is a renaming, not a move.
 template <bool GRAD>
 __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, float* __restrict__ wavep_out) {
   const LossDims d = a.d;
@@ -113,28 +120,25 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   float* __restrict__ hb = a.Hb + (size_t)it.img * HW * 8;
   const float nx = (float)(min(gx + 1, d.W - 1) - max(gx - 1, 0) + 1);
   constexpr int HAL = GRAD ? 2 : 1;
+  const int r_first = y0 - HAL, r_last = y1 - 1 + HAL;
 
-  float Hm[2][3][5], Nz[2][3];   // horizontal moment sums / non-zero counts of rows r-2, r-1
-  float Ch[2][3][3];             // horizontal sums of (a, b, c) of rows r-3, r-2
-  float X[2][3], Y[2][3], Iv[2]; // centre values of rows r-2, r-1 and 1 / (D + 1e-10)
-  float Mp[3];                   // mask of row r-2
+  // rings, slot = (row - r_first) mod 3.  moments per channel: x, y, xx + yy, xy
+  float Hm[3][3][4], Nz[3][3], Ch[3][3][3], X[3][3], Y[3][3], Iv[3], Mk[3][3];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     Iv[k] = 0.f;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      Nz[k][ch] = X[k][ch] = Y[k][ch] = 0.f;
+      Nz[k][ch] = X[k][ch] = Y[k][ch] = Mk[k][ch] = 0.f;
 #pragma unroll
-      for (int m = 0; m < 5; ++m) Hm[k][ch][m] = 0.f;
+      for (int m = 0; m < 4; ++m) Hm[k][ch][m] = 0.f;
 #pragma unroll
       for (int m = 0; m < 3; ++m) Ch[k][ch][m] = 0.f;
     }
   }
-  Mp[0] = Mp[1] = Mp[2] = 0.f;
   float sA = 0.f, sM = 0.f, sV = 0.f;
 
-  // software prefetch of the next row's raw values
-  float4 na = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 na = make_float4(0.f, 0.f, 0.f, 0.f);  // software prefetch of the next row's raw values
   f3 ns{0.f, 0.f, 0.f};
   auto fetch = [&](int r) {
     na = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -149,84 +153,78 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
       ns = ld3(sp + p * C3);
     }
   };
-  fetch(y0 - HAL);
-  for (int r = y0 - HAL; r <= y1 - 1 + HAL; ++r) {
+
+  auto step = [&](int r, auto ph) {
+    constexpr int S0 = decltype(ph)::value;            // slot of row r
+    constexpr int S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;  // slots of rows r-1, r-2 (r-3 shares S0)
     const float4 ca = na;
     const f3 cs = ns;
-    if (r + 1 <= y1 - 1 + HAL) fetch(r + 1);
-    const bool row_in = r >= 0 && r < d.H;  // wave-uniform
+    if (r + 1 <= r_last) fetch(r + 1);
     // ---- row r: values, horizontal sums
-    float x[3], y[3], hc[3][5], nzc[3], inv = 0.f;
-    if (row_in) {
-      inv = col_in ? fast_rcp(ca.w + 1e-10f) : 0.f;
-      x[0] = ca.x * inv; x[1] = ca.y * inv; x[2] = ca.z * inv;  // 0 outside the image (ca = 0)
-      y[0] = cs.x; y[1] = cs.y; y[2] = cs.z;
+    if (r >= 0 && r < d.H) {  // wave-uniform
+      const float inv = col_in ? fast_rcp(ca.w + 1e-10f) : 0.f;
+      Iv[S0] = inv;
+      const float xv[3] = {ca.x * inv, ca.y * inv, ca.z * inv}, yv[3] = {cs.x, cs.y, cs.z};  // 0 outside the image
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        hc[ch][0] = hsum3(x[ch]);
-        hc[ch][1] = hsum3(y[ch]);
-        hc[ch][2] = hsum3(x[ch] * x[ch]);
-        hc[ch][3] = hsum3(y[ch] * y[ch]);
-        hc[ch][4] = hsum3(x[ch] * y[ch]);
-        const float nz = (x[ch] == 0.0f) ? 0.0f : 1.0f;
-        nzc[ch] = nz + (lane_left(nz) + lane_right(nz));
+        X[S0][ch] = xv[ch];
+        Y[S0][ch] = yv[ch];
+        Hm[S0][ch][0] = hsum3(xv[ch]);
+        Hm[S0][ch][1] = hsum3(yv[ch]);
+        Hm[S0][ch][2] = hsum3(xv[ch] * xv[ch] + yv[ch] * yv[ch]);
+        Hm[S0][ch][3] = hsum3(xv[ch] * yv[ch]);
+        const float nz = (xv[ch] == 0.0f) ? 0.0f : 1.0f;
+        Nz[S0][ch] = nz + (lane_left(nz) + lane_right(nz));
       }
     } else {
+      Iv[S0] = 0.f;
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        x[ch] = y[ch] = nzc[ch] = 0.f;
+        X[S0][ch] = Y[S0][ch] = Nz[S0][ch] = 0.f;
 #pragma unroll
-        for (int m = 0; m < 5; ++m) hc[ch][m] = 0.f;
+        for (int m = 0; m < 4; ++m) Hm[S0][ch][m] = 0.f;
       }
     }
     // ---- row q = r - 1: windowed moments -> SSIM value, derivative coefficients, mask, sums
     const int q = r - 1;
-    float chc[3][3], mq[3];
-    if (r - (y0 - HAL) >= 2) {
-      const bool q_in = q >= 0 && q < d.H;
-      const bool pix_in = q_in && col_in;
+    if (r - r_first >= 2) {
+      const bool pix_in = q >= 0 && q < d.H && col_in;
       const bool own = own_col && q >= y0 && q < y1;
       const float rcnt = 1.0f / (rows_in(q, d.H) * nx);  // k * fl(1/k) == 1 exactly for k = 4, 6, 9
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         float ca_ = 0.f, cb_ = 0.f, cc_ = 0.f;
-        const float v = ssim_point<GRAD>(vsum3(Hm[0][ch][0], Hm[1][ch][0], hc[ch][0]), vsum3(Hm[0][ch][1], Hm[1][ch][1], hc[ch][1]),
-                                         vsum3(Hm[0][ch][2], Hm[1][ch][2], hc[ch][2]), vsum3(Hm[0][ch][3], Hm[1][ch][3], hc[ch][3]),
-                                         vsum3(Hm[0][ch][4], Hm[1][ch][4], hc[ch][4]), ca_, cb_, cc_);
-        const float m = ((Nz[0][ch] + Nz[1][ch]) + nzc[ch]) * rcnt;
-        mq[ch] = m;
+        const float v = ssim_point<GRAD>(vsum3(Hm[S2][ch][0], Hm[S1][ch][0], Hm[S0][ch][0]),
+                                         vsum3(Hm[S2][ch][1], Hm[S1][ch][1], Hm[S0][ch][1]),
+                                         vsum3(Hm[S2][ch][2], Hm[S1][ch][2], Hm[S0][ch][2]),
+                                         vsum3(Hm[S2][ch][3], Hm[S1][ch][3], Hm[S0][ch][3]), ca_, cb_, cc_);
+        const float m = ((Nz[S2][ch] + Nz[S1][ch]) + Nz[S0][ch]) * rcnt;
+        Mk[S1][ch] = m;
         if (own) {
           sV += v;
-          sA += m * fabsf(X[1][ch] - Y[1][ch]);
+          sA += m * fabsf(X[S1][ch] - Y[S1][ch]);
           sM += m;
         }
-        if constexpr (GRAD) {
-          chc[ch][0] = hsum3(pix_in ? ca_ : 0.f);
-          chc[ch][1] = hsum3(pix_in ? cb_ : 0.f);
-          chc[ch][2] = hsum3(pix_in ? cc_ : 0.f);
+        if constexpr (GRAD) {  // coefficients of row q overwrite those of row q - 3 (same slot)
+          Ch[S1][ch][0] = hsum3(pix_in ? ca_ : 0.f);
+          Ch[S1][ch][1] = hsum3(pix_in ? cb_ : 0.f);
+          Ch[S1][ch][2] = hsum3(pix_in ? cc_ : 0.f);
         }
       }
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        mq[ch] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) chc[ch][m] = 0.f;
-      }
     }
-    // ---- row p = r - 2: backward seeds
+    // ---- row p = r - 2: backward seeds (coefficient rows p-1, p, p+1 sit in slots S0, S2, S1)
     if constexpr (GRAD) {
       const int p = r - 2;
       if (own_col && p >= y0 && p < y1) {
         float hA[3], hB[3], wA = 0.f, wB = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float xv = X[0][ch], yv = Y[0][ch];
-          const float rr = vsum3(Ch[0][ch][0], Ch[1][ch][0], chc[ch][0]) +
-                           2.0f * vsum3(Ch[0][ch][1], Ch[1][ch][1], chc[ch][1]) * xv +
-                           vsum3(Ch[0][ch][2], Ch[1][ch][2], chc[ch][2]) * yv;
-          hA[ch] = (a.kL1 * Mp[ch] * sgn(xv - yv)) * Iv[0];
-          hB[ch] = rr * Iv[0];
+          const float xv = X[S2][ch], yv = Y[S2][ch];
+          const float rr = vsum3(Ch[S0][ch][0], Ch[S2][ch][0], Ch[S1][ch][0]) +
+                           2.0f * vsum3(Ch[S0][ch][1], Ch[S2][ch][1], Ch[S1][ch][1]) * xv +
+                           vsum3(Ch[S0][ch][2], Ch[S2][ch][2], Ch[S1][ch][2]) * yv;
+          hA[ch] = (a.kL1 * Mk[S2][ch] * sgn(xv - yv)) * Iv[S2];
+          hB[ch] = rr * Iv[S2];
           wA += hA[ch] * xv;
           wB += hB[ch] * xv;
         }
@@ -235,19 +233,13 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
         o[1] = make_float4(hB[0], hB[1], hB[2], wB);
       }
     }
-    // ---- slide the windows
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-#pragma unroll
-      for (int m = 0; m < 5; ++m) { Hm[0][ch][m] = Hm[1][ch][m]; Hm[1][ch][m] = hc[ch][m]; }
-#pragma unroll
-      for (int m = 0; m < 3; ++m) { Ch[0][ch][m] = Ch[1][ch][m]; Ch[1][ch][m] = chc[ch][m]; }
-      Nz[0][ch] = Nz[1][ch]; Nz[1][ch] = nzc[ch];
-      X[0][ch] = X[1][ch]; X[1][ch] = x[ch];
-      Y[0][ch] = Y[1][ch]; Y[1][ch] = y[ch];
-      Mp[ch] = mq[ch];
-    }
-    Iv[0] = Iv[1]; Iv[1] = inv;
+  };
+
+  fetch(r_first);
+  for (int r = r_first; r <= r_last; r += 3) {
+    step(r, IC<0>{});
+    if (r + 1 <= r_last) step(r + 1, IC<1>{});
+    if (r + 2 <= r_last) step(r + 2, IC<2>{});
   }
   sA = wave_sum(sA); sM = wave_sum(sM); sV = wave_sum(sV);
   if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sA, sM, sV, 0.f);
@@ -274,25 +266,24 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
   const float* __restrict__ g1p = a.G + o1;
   const float* __restrict__ tp = a.tgt + (size_t)b * HW * 3;
   constexpr int HAL = GRAD ? 2 : 1;
+  const int r_first = y0 - HAL, r_last = y1 - 1 + HAL;
   const float ku = a.kE * (1.0f - kAlpha) * (-0.5f);
   const float kl = a.kE * kAlpha;
 
-  // moment order per channel: t, tt, x0, x0x0, x0t, x1, x1x1, x1t
-  float Hm[2][3][8];
-  float Ch[2][3][6];                      // (a0, b0, c0, a1, b1, c1), already scaled by the selection
-  float X0[2][3], X1[2][3], T[2][3];      // centre values of rows r-2, r-1
-  float Sel[3];                           // selection of row r-2
+  // rings, slot = (row - r_first) mod 3.  moments per channel: t, x0, x1, x0x0 + tt, x1x1 + tt, x0t, x1t
+  float Hm[3][3][7];
+  float Ch[3][3][6];  // (a0, b0, c0, a1, b1, c1), already scaled by the selection
+  float X0[3][3], X1[3][3], T[3][3], Sel[3][3];
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      X0[k][ch] = X1[k][ch] = T[k][ch] = 0.f;
+      X0[k][ch] = X1[k][ch] = T[k][ch] = Sel[k][ch] = 0.f;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) Hm[k][ch][m] = 0.f;
+      for (int m = 0; m < 7; ++m) Hm[k][ch][m] = 0.f;
 #pragma unroll
       for (int m = 0; m < 6; ++m) Ch[k][ch][m] = 0.f;
     }
-  Sel[0] = Sel[1] = Sel[2] = 0.f;
   float sE = 0.f;
 
   f3 n0{0.f, 0.f, 0.f}, n1{0.f, 0.f, 0.f}, nt{0.f, 0.f, 0.f};
@@ -305,61 +296,56 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
       nt = ld3(tp + p);
     }
   };
-  fetch(y0 - HAL);
-  for (int r = y0 - HAL; r <= y1 - 1 + HAL; ++r) {
+
+  auto step = [&](int r, auto ph) {
+    constexpr int S0 = decltype(ph)::value;
+    constexpr int S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;
     const float x0[3] = {n0.x, n0.y, n0.z}, x1[3] = {n1.x, n1.y, n1.z}, t[3] = {nt.x, nt.y, nt.z};
-    if (r + 1 <= y1 - 1 + HAL) fetch(r + 1);
-    const bool row_in = r >= 0 && r < d.H;
-    float hc[3][8];
-    if (row_in) {
+    if (r + 1 <= r_last) fetch(r + 1);
+    if (r >= 0 && r < d.H) {
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        hc[ch][0] = hsum3(t[ch]);
-        hc[ch][1] = hsum3(t[ch] * t[ch]);
-        hc[ch][2] = hsum3(x0[ch]);
-        hc[ch][3] = hsum3(x0[ch] * x0[ch]);
-        hc[ch][4] = hsum3(x0[ch] * t[ch]);
-        hc[ch][5] = hsum3(x1[ch]);
-        hc[ch][6] = hsum3(x1[ch] * x1[ch]);
-        hc[ch][7] = hsum3(x1[ch] * t[ch]);
+        X0[S0][ch] = x0[ch]; X1[S0][ch] = x1[ch]; T[S0][ch] = t[ch];
+        const float tt = t[ch] * t[ch];
+        Hm[S0][ch][0] = hsum3(t[ch]);
+        Hm[S0][ch][1] = hsum3(x0[ch]);
+        Hm[S0][ch][2] = hsum3(x1[ch]);
+        Hm[S0][ch][3] = hsum3(x0[ch] * x0[ch] + tt);
+        Hm[S0][ch][4] = hsum3(x1[ch] * x1[ch] + tt);
+        Hm[S0][ch][5] = hsum3(x0[ch] * t[ch]);
+        Hm[S0][ch][6] = hsum3(x1[ch] * t[ch]);
       }
     } else {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
+      for (int ch = 0; ch < 3; ++ch) {
+        X0[S0][ch] = X1[S0][ch] = T[S0][ch] = 0.f;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) hc[ch][m] = 0.f;
+        for (int m = 0; m < 7; ++m) Hm[S0][ch][m] = 0.f;
+      }
     }
     const int q = r - 1;
-    float chc[3][6], selq[3];
-    if (r - (y0 - HAL) >= 2) {
+    if (r - r_first >= 2) {
       const bool pix_in = q >= 0 && q < d.H && col_in;
       const bool own = own_col && q >= y0 && q < y1;
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        float mm[8];
+        float mm[7];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) mm[m] = vsum3(Hm[0][ch][m], Hm[1][ch][m], hc[ch][m]);
+        for (int m = 0; m < 7; ++m) mm[m] = vsum3(Hm[S2][ch][m], Hm[S1][ch][m], Hm[S0][ch][m]);
         float a0 = 0.f, b0 = 0.f, c0 = 0.f, a1 = 0.f, b1 = 0.f, c1 = 0.f;
-        const float v0 = ssim_point<GRAD>(mm[2], mm[0], mm[3], mm[1], mm[4], a0, b0, c0);
-        const float v1 = ssim_point<GRAD>(mm[5], mm[0], mm[6], mm[1], mm[7], a1, b1, c1);
-        const float e0 = kAlpha * fabsf(X0[1][ch] - T[1][ch]) + (1.0f - kAlpha) * clip01_half(v0);
-        const float e1 = kAlpha * fabsf(X1[1][ch] - T[1][ch]) + (1.0f - kAlpha) * clip01_half(v1);
+        const float v0 = ssim_point<GRAD>(mm[1], mm[0], mm[3], mm[5], a0, b0, c0);
+        const float v1 = ssim_point<GRAD>(mm[2], mm[0], mm[4], mm[6], a1, b1, c1);
+        const float e0 = kAlpha * fabsf(X0[S1][ch] - T[S1][ch]) + (1.0f - kAlpha) * clip01_half(v0);
+        const float e1 = kAlpha * fabsf(X1[S1][ch] - T[S1][ch]) + (1.0f - kAlpha) * clip01_half(v1);
         const bool first = e0 <= e1;  // tf.minimum ties -> either (equal values)
-        selq[ch] = first ? 1.0f : 0.0f;
+        Sel[S1][ch] = first ? 1.0f : 0.0f;
         if (own) sE += first ? e0 : e1;
         if constexpr (GRAD) {
           const float u0 = (pix_in && first) ? ku * clip01_half_pass(v0) : 0.f;
           const float u1 = (pix_in && !first) ? ku * clip01_half_pass(v1) : 0.f;
-          chc[ch][0] = hsum3(a0 * u0); chc[ch][1] = hsum3(b0 * u0); chc[ch][2] = hsum3(c0 * u0);
-          chc[ch][3] = hsum3(a1 * u1); chc[ch][4] = hsum3(b1 * u1); chc[ch][5] = hsum3(c1 * u1);
+          Ch[S1][ch][0] = hsum3(a0 * u0); Ch[S1][ch][1] = hsum3(b0 * u0); Ch[S1][ch][2] = hsum3(c0 * u0);
+          Ch[S1][ch][3] = hsum3(a1 * u1); Ch[S1][ch][4] = hsum3(b1 * u1); Ch[S1][ch][5] = hsum3(c1 * u1);
         }
-      }
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        selq[ch] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) chc[ch][m] = 0.f;
       }
     }
     if constexpr (GRAD) {
@@ -368,30 +354,26 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
         float d0[3], d1[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float tv = T[0][ch], xa = X0[0][ch], xb = X1[0][ch];
-          d0[ch] = kl * Sel[ch] * sgn(xa - tv) +
-                   (vsum3(Ch[0][ch][0], Ch[1][ch][0], chc[ch][0]) + 2.0f * vsum3(Ch[0][ch][1], Ch[1][ch][1], chc[ch][1]) * xa +
-                    vsum3(Ch[0][ch][2], Ch[1][ch][2], chc[ch][2]) * tv);
-          d1[ch] = kl * (1.0f - Sel[ch]) * sgn(xb - tv) +
-                   (vsum3(Ch[0][ch][3], Ch[1][ch][3], chc[ch][3]) + 2.0f * vsum3(Ch[0][ch][4], Ch[1][ch][4], chc[ch][4]) * xb +
-                    vsum3(Ch[0][ch][5], Ch[1][ch][5], chc[ch][5]) * tv);
+          const float tv = T[S2][ch], xa = X0[S2][ch], xb = X1[S2][ch];
+          d0[ch] = kl * Sel[S2][ch] * sgn(xa - tv) +
+                   (vsum3(Ch[S0][ch][0], Ch[S2][ch][0], Ch[S1][ch][0]) + 2.0f * vsum3(Ch[S0][ch][1], Ch[S2][ch][1], Ch[S1][ch][1]) * xa +
+                    vsum3(Ch[S0][ch][2], Ch[S2][ch][2], Ch[S1][ch][2]) * tv);
+          d1[ch] = kl * (1.0f - Sel[S2][ch]) * sgn(xb - tv) +
+                   (vsum3(Ch[S0][ch][3], Ch[S2][ch][3], Ch[S1][ch][3]) + 2.0f * vsum3(Ch[S0][ch][4], Ch[S2][ch][4], Ch[S1][ch][4]) * xb +
+                    vsum3(Ch[S0][ch][5], Ch[S2][ch][5], Ch[S1][ch][5]) * tv);
         }
         const size_t pp = ((size_t)p * d.W + gx) * 3;
         st3(a.dG + o0 + pp, d0[0], d0[1], d0[2]);
         st3(a.dG + o1 + pp, d1[0], d1[1], d1[2]);
       }
     }
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) { Hm[0][ch][m] = Hm[1][ch][m]; Hm[1][ch][m] = hc[ch][m]; }
-#pragma unroll
-      for (int m = 0; m < 6; ++m) { Ch[0][ch][m] = Ch[1][ch][m]; Ch[1][ch][m] = chc[ch][m]; }
-      X0[0][ch] = X0[1][ch]; X0[1][ch] = x0[ch];
-      X1[0][ch] = X1[1][ch]; X1[1][ch] = x1[ch];
-      T[0][ch] = T[1][ch]; T[1][ch] = t[ch];
-      Sel[ch] = selq[ch];
-    }
+  };
+
+  fetch(r_first);
+  for (int r = r_first; r <= r_last; r += 3) {
+    step(r, IC<0>{});
+    if (r + 1 <= r_last) step(r + 1, IC<1>{});
+    if (r + 2 <= r_last) step(r + 2, IC<2>{});
   }
   sE = wave_sum(sE);
   if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sE, 0.f, 0.f, 0.f);

@@ -1,0 +1,59 @@
+// Microbench: issue rate of v_fma_f32 vs v_pk_fma_f32 vs v_mov_b32_dpp on gfx950 (full chip, 8 waves/SIMD).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float float2v __attribute__((ext_vector_type(2)));
+constexpr int ITERS = 2048;
+__global__ __launch_bounds__(256) void k_fma(float* out, float a, float b) {
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = threadIdx.x + i;
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b));
+  float s = 0; for (int i = 0; i < 8; ++i) s += x[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_pkfma(float* out, float a, float b) {
+  float2v x[8], av = {a, a}, bv = {b, b};
+  for (int i = 0; i < 8; ++i) x[i] = float2v{(float)threadIdx.x + i, (float)i};
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(av), "v"(bv));
+  float s = 0; for (int i = 0; i < 8; ++i) s += x[i].x + x[i].y;
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_dpp(float* out, float a, float b) {
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = threadIdx.x + i;
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x[i]) : "v"(a));
+  float s = 0; for (int i = 0; i < 8; ++i) s += x[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_rcp(float* out, float a, float b) {
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = threadIdx.x + i + 1;
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
+  float s = 0; for (int i = 0; i < 8; ++i) s += x[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <typename K> void run(const char* name, K k, int blocks, float* out) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+  (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  double winstr = (double)blocks * 4 * ITERS * 8;  // wave-instructions
+  double per_simd = winstr / 1024.0;
+  printf("%-10s blocks %5d: %.3f ms, %.2f cycles per wave-instruction per SIMD (2.4 GHz)\n", name, blocks, ms, ms * 1e-3 * 2.4e9 / per_simd);
+}
+int main() {
+  float* out; (void)hipMalloc(&out, 256 * 8 * 256 * 4 * 4);
+  for (int blocks : {256, 512, 2048}) {   // 1, 2, 8 waves per SIMD
+    run("v_fma", k_fma, blocks, out); run("v_pk_fma", k_pkfma, blocks, out); run("add_dpp", k_dpp, blocks, out); run("v_rcp", k_rcp, blocks, out);
+  }
+  return 0;
+}
