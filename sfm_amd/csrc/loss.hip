@@ -31,7 +31,11 @@
 
 namespace sfm {
 
-constexpr int SR = 8;  // splat: reach of the scan window around the shifted tile
+constexpr int kCacheTX = 2, kCacheTY = 4, kCacheW = 2 * kCacheTX + 1, kCacheH = 2 * kCacheTY + 1;  // LDS-cached table window (tiles)
+// splat: reach of a tile's scan window = ceil(half-range of the tile's displacement) + kReachAdd, clamped.
+// Scanning is cheap (~8 us per 1.0 of redundancy at c2) and a flagged image costs its consumers a second
+// accumulator read, so the reach is generous.
+constexpr int kReachAdd = 4, kReachMin = 6, kReachMax = 16;
 
 // ------------------------------------------------------------------ fused warp forward
 // The forward splat (utils.py:419-470) without global atomics in the common case.
@@ -39,12 +43,13 @@ constexpr int SR = 8;  // splat: reach of the scan window around the shifted til
 // A workgroup OWNS a destination tile of STW x STH pixels of one (scale, source, batch item)
 // image and keeps its (sum g*rgb, sum g) accumulators in LDS.  It scans the window of target
 // pixels that can land in the tile - the tile moved back by the tile's estimated displacement
-// (`shift`, one int2 per tile, written by loss_tile_shift_kernel) and grown by SR pixels -
+// and grown by the tile's reach (`shift` = (shift_x, shift_y, reach_x, reach_y), one int4 per tile,
+// written by loss_tile_shift_kernel from the spread of the displacement over the tile) -
 // evaluates the geometry of each scanned pixel and adds the corners that fall inside its own
-// tile with LDS atomics (ds_add_f32).  The tile is then written to Acc with plain 16-byte
+// tile with LDS atomics (ds_add_f64).  The tile is then written to Acc with plain 16-byte
 // stores: no memset of Acc, no global atomics, every Acc element written exactly once.
 //
-// Exactness does not depend on the shift table or on SR.  Each target pixel also has a HOME
+// Exactness does not depend on the table.  Each target pixel also has a HOME
 // workgroup (the one whose tile contains the pixel itself).  For each of the pixel's four
 // corners the home workgroup evaluates the same window predicate the owner of the corner's
 // tile uses; a corner whose owner does not scan the pixel ("overflow", rare for smooth
@@ -52,18 +57,22 @@ constexpr int SR = 8;  // splat: reach of the scan window around the shifted til
 // global atomics and the image's flag is raised; consumers read Acc + Ovf for flagged
 // images.  Every (pixel, corner) contribution is therefore counted exactly once.
 // The home workgroup also performs the 4-tap gather of the pixel (utils.py:297-335) -> G.
-__device__ __forceinline__ bool in_scan_window(int u, int v, int tx, int ty, int2 sft) {
-  const int xl = tx * STW - sft.x - SR, yl = ty * STH - sft.y - SR;
-  return u >= xl && u < xl + STW + 2 * SR && v >= yl && v < yl + STH + 2 * SR;
+// scan window (x_lo, x_hi, y_lo, y_hi), half-open, of the owner of tile (tx, ty) with table entry sft
+__device__ __forceinline__ int4 scan_rect(int tx, int ty, int4 sft) {
+  const int xl = tx * STW - sft.x - sft.z, yl = ty * STH - sft.y - sft.w;
+  return make_int4(xl, xl + STW + 2 * sft.z, yl, yl + STH + 2 * sft.w);
 }
 
-// One thread per (image, tile): mid-range of the displacement (x - u, y - v) over a 3x3 grid of
-// sample pixels of the tile.  Any table is correct; a good one keeps the overflow rare.
+// One thread per (image, tile): mid-range and half-range of the displacement (x - u, y - v) over a
+// 3x3 grid of sample pixels of the tile -> shift and reach of the tile's scan window.  A pixel at u
+// with displacement in [lo, hi] has corners floor(u + dx) + {0, 1}: reach = half-range + 1.5 covers the
+// sampled spread; the additive margin (kReachAdd) covers the variation between samples.  Any table is correct; a good one
+// keeps the overflow rare and the scan small.
 __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __restrict__ depth,
                                                                  const float* __restrict__ trans,
                                                                  const float* __restrict__ params, LossDims d,
                                                                  float step_x, float step_y, int tiles_x, int tiles_y,
-                                                                 int2* __restrict__ shift) {
+                                                                 int4* __restrict__ shift, int radd, int rmin, int rmax) {
   const int ntile = tiles_x * tiles_y;
   const long total = (long)d.S * d.N * d.B * ntile;
   const long k = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -92,9 +101,12 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
       lo_y = fminf(lo_y, ddy); hi_y = fmaxf(hi_y, ddy);
     }
   const float mx = 0.5f * (lo_x + hi_x), my = 0.5f * (lo_y + hi_y);
-  int2 o;
+  const float hx = 0.5f * (hi_x - lo_x), hy = 0.5f * (hi_y - lo_y);
+  int4 o;
   o.x = (mx == mx) ? (int)rintf(fminf(fmaxf(mx, -32768.0f), 32767.0f)) : 0;
   o.y = (my == my) ? (int)rintf(fminf(fmaxf(my, -32768.0f), 32767.0f)) : 0;
+  o.z = (hx == hx) ? (int)fminf(fmaxf(ceilf(hx) + (float)radd, (float)rmin), (float)rmax) : rmin;
+  o.w = (hy == hy) ? (int)fminf(fmaxf(ceilf(hy) + (float)radd, (float)rmin), (float)rmax) : rmin;
   shift[k] = o;
 }
 
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
                                                                  const float* __restrict__ trans,
                                                                  const float* __restrict__ params, LossDims d,
                                                                  float step_x, float step_y,
-                                                                 const int2* __restrict__ shift, float* __restrict__ G,
+                                                                 const int4* __restrict__ shift, float* __restrict__ G,
                                                                  float* __restrict__ Acc, float* __restrict__ Ovf,
                                                                  int* __restrict__ flags) {
   constexpr int TP = STW * STH;
@@ -113,24 +125,34 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
   // instruction in ~9 cycles while ds_add_f32 takes ~190 (profiles/r01_lds_atomic_microbench.txt);
   // the float -> double conversion is exact and the sums lose nothing before the final rounding.
   __shared__ double acc[4 * TP];
+  __shared__ int4 tcache[kCacheW * kCacheH];
   const int tx = blockIdx.x, ty = blockIdx.y, tiles_x = gridDim.x;
   const int img = blockIdx.z;  // (s*N + i)*B + b
   const int b = img % d.B, si = img / d.B, i = si % d.N, s = si / d.N;
   const int HW = d.H * d.W, C3 = 3 * d.N;
   const int ng = d.N < 2 ? d.N : 2;
-  const int2* __restrict__ stab = shift + (size_t)img * (gridDim.x * gridDim.y);
-  const int2 mine = stab[ty * tiles_x + tx];
+  const int4* __restrict__ stab = shift + (size_t)img * (gridDim.x * gridDim.y);
+  const int4 mine = stab[ty * tiles_x + tx];
   const int x0 = tx * STW, y0 = ty * STH;
   const int x1 = min(x0 + STW, d.W), y1 = min(y0 + STH, d.H);
   // scan window clipped to the image
-  const int sxl = max(x0 - mine.x - SR, 0), sxh = min(x0 - mine.x + STW + SR, d.W);
-  const int syl = max(y0 - mine.y - SR, 0), syh = min(y0 - mine.y + STH + SR, d.H);
+  const int sxl = max(x0 - mine.x - mine.z, 0), sxh = min(x0 - mine.x + STW + mine.z, d.W);
+  const int syl = max(y0 - mine.y - mine.w, 0), syh = min(y0 - mine.y + STH + mine.w, d.H);
   const int RW = max(sxh - sxl, 0), RH = max(syh - syl, 0);
   const int n_scan = RW * RH;
   const bool home_covered = (RW > 0 && RH > 0 && sxl <= x0 && sxh >= x1 && syl <= y0 && syh >= y1);
   const int n_all = n_scan + (home_covered ? 0 : TP);
   const float inv_rw = RW > 0 ? 1.0f / (float)RW : 0.0f;
   for (int k = threadIdx.x; k < 4 * TP; k += kBlock) acc[k] = 0.0;
+  // scan windows of the tiles this tile's pixels can land in (the neighbourhood of where its centre
+  // lands), cached in LDS for the overflow test; anything further away is looked up in memory
+  const int ctx0 = min(max(x0 + STW / 2 + mine.x, 0), d.W - 1) / STW - kCacheTX;
+  const int cty0 = min(max(y0 + STH / 2 + mine.y, 0), d.H - 1) / STH - kCacheTY;
+  if (threadIdx.x < kCacheW * kCacheH) {
+    const int cx_ = ctx0 + (int)threadIdx.x % kCacheW, cy_ = cty0 + (int)threadIdx.x / kCacheW;
+    if (cx_ >= 0 && cx_ < tiles_x && cy_ >= 0 && cy_ < (int)gridDim.y)
+      tcache[threadIdx.x] = scan_rect(cx_, cy_, stab[cy_ * tiles_x + cx_]);
+  }
   __syncthreads();
 
   const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
       u = sxl + (k - ly * RW);
       v = syl + ly;
       scan = true;
-    } else {  // home pixels the window does not cover (|shift| > SR)
+    } else {  // home pixels the window does not cover (|shift| > reach)
       const int kk = k - n_scan;
       u = x0 + (kk & (STW - 1));
       v = y0 + (kk / STW);
@@ -178,17 +200,36 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
           atomicAdd(&acc[3 * TP + l], (double)w);
         }
       }
-      if (home) {
-        const int dtx = cx[q] / STW, dty = cy[q] / STH;
-        const int2 sft = stab[dty * tiles_x + dtx];
-        if (!in_scan_window(u, v, dtx, dty, sft)) {
-          float* o = ovf + ((size_t)cy[q] * d.W + cx[q]) * 4;
-          atomicAdd(o + 0, tv.x * w);
-          atomicAdd(o + 1, tv.y * w);
-          atomicAdd(o + 2, tv.z * w);
-          atomicAdd(o + 3, w);
-          flagged = true;
-        }
+    }
+    if (home) {
+      // which of the four corners does the owner of its tile NOT scan?  (corners usually share a tile)
+      auto covered = [&](unsigned dtx, unsigned dty) -> bool {
+        const unsigned ox = dtx - (unsigned)ctx0, oy = dty - (unsigned)cty0;
+        int4 r;
+        if (ox < (unsigned)kCacheW && oy < (unsigned)kCacheH)
+          r = tcache[oy * kCacheW + ox];
+        else
+          r = scan_rect((int)dtx, (int)dty, stab[dty * tiles_x + dtx]);
+        return u >= r.x && u < r.y && v >= r.z && v < r.w;
+      };
+      const unsigned tx0 = (unsigned)c.x0 / STW, tx1 = (unsigned)c.x1 / STW;
+      const unsigned ty0 = (unsigned)c.y0 / STH, ty1 = (unsigned)c.y1 / STH;
+      const bool k00 = covered(tx0, ty0);
+      const bool k01 = (ty1 == ty0) ? k00 : covered(tx0, ty1);
+      const bool k10 = (tx1 == tx0) ? k00 : covered(tx1, ty0);
+      const bool k11 = (tx1 == tx0) ? k01 : ((ty1 == ty0) ? k10 : covered(tx1, ty1));
+      const unsigned miss = (k00 ? 0u : 1u) | (k01 ? 0u : 2u) | (k10 ? 0u : 4u) | (k11 ? 0u : 8u);
+      if (miss) {  // rare: overflow path
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((miss >> q) & 1u) {
+            float* o = ovf + ((size_t)cy[q] * d.W + cx[q]) * 4;
+            atomicAdd(o + 0, tv.x * sw.g[q]);
+            atomicAdd(o + 1, tv.y * sw.g[q]);
+            atomicAdd(o + 2, tv.z * sw.g[q]);
+            atomicAdd(o + 3, sw.g[q]);
+          }
+        flagged = true;
       }
     }
     if (home && i < ng) {  // gather (utils.py:297-335)
@@ -463,12 +504,13 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
   hipStream_t stream = (hipStream_t)stream_;
   const LossLayout l = loss_layout(d);
   const LossWs& w = l.w;
-  int2* shift = reinterpret_cast<int2*>(ws + w.shift);
+  int4* shift = reinterpret_cast<int4*>(ws + w.shift);
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   { StageTimer t(ST_SHIFT, stream);
   const long n = (long)w.n_img * w.stiles_x * w.stiles_y;
   hipLaunchKernelGGL(loss_tile_shift_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, depth,
-                     trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift); }
+                     trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift,
+                     kReachAdd, kReachMin, kReachMax); }
   { StageTimer t(ST_WARP_FWD, stream);
   hipLaunchKernelGGL(loss_splat_tile_kernel, dim3(w.stiles_x, w.stiles_y, w.n_img), dim3(kBlock), 0, stream, tgt, src,
                      depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), shift, ws + w.G, ws + w.Acc, ws + w.Ovf,

@@ -77,7 +77,7 @@ static inline LossWs loss_ws(const LossDims& d, const StencilPlan& sp) {
   w.wavep = o; o += up4((size_t)(sp.n_splat + sp.n_gather) * kWaveTerms);
   w.dPp = o; o += up4((size_t)d.S * d.N * d.B * w.nblk_bwd * 12);
   w.coef = o; o += 64;
-  w.shift = o; o += up4((size_t)w.n_img * w.stiles_x * w.stiles_y * 2);
+  w.shift = o; o += (size_t)w.n_img * w.stiles_x * w.stiles_y * 4;
   w.flags = o; o += up4((size_t)w.n_img);
   w.total = o;
   return w;
