@@ -24,7 +24,7 @@
 //   tgt [B,H,W,3]   src [B,H,W,3N]   depth [S,B,H,W]   trans [S,B,H,W,3N]
 //   G   [S,2,B,H,W,3]     gathered sources 0,1 (the only ones line 168 reads)
 //   Acc [S,N,B,H,W,4]     splat accumulators (sum g*rgb, sum g): one 16-B unit per pixel
-//   Hb  [S,N,B,H,W,8]     backward seeds per destination pixel, two parts (hA[3], sum_c hA*Sp, hB[3], sum_c hB*Sp)
+//   Hb  [2][S,N,B,H,W,4]  backward seeds per destination pixel, two parts: (hA[3], sum_c hA*Sp) and (hB[3], sum_c hB*Sp)
 //   dG  [S,2,B,H,W,3]     backward: dL/dG_i for gloss = 1
 #include "loss_common.h"
 #include <cstdlib>
@@ -344,12 +344,13 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
   const size_t sb = ((size_t)s * d.B + b) * HW;
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
   const float gl = coef[0];  // dL/d loss
+  const size_t hb_plane = (size_t)d.S * d.N * d.B * HW * 4;
   float ddsum[kLossPPT];
 #pragma unroll
   for (int it = 0; it < kLossPPT; ++it) ddsum[it] = 0.0f;
   for (int i = 0; i < d.N; ++i) {
     const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-    const float* hb = Hb + (((size_t)s * d.N + i) * d.B + b) * HW * 8;
+    const float* hb = Hb + (((size_t)s * d.N + i) * d.B + b) * HW * 4;  // part A; part B one plane further
     const float kv = coef[1 + s * d.N + i];  // gloss * kV(s, i)
     // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
     float4* ovz = flags[(s * d.N + i) * d.B + b]
@@ -386,8 +387,8 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
         float dgk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float4 ha = *reinterpret_cast<const float4*>(hb + (size_t)idx[k] * 8);
-          const float4 hv = *reinterpret_cast<const float4*>(hb + (size_t)idx[k] * 8 + 4);
+          const float4 ha = *reinterpret_cast<const float4*>(hb + (size_t)idx[k] * 4);
+          const float4 hv = *reinterpret_cast<const float4*>(hb + hb_plane + (size_t)idx[k] * 4);
           const float da = ((ha.x * tv.x + ha.y * tv.y) + ha.z * tv.z) - ha.w;
           const float dv = ((hv.x * tv.x + hv.y * tv.y) + hv.z * tv.z) - hv.w;
           dgk[k] = (gl * da + kv * dv) * sw.g[k];

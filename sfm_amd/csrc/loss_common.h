@@ -45,7 +45,7 @@ static inline StencilPlan stencil_plan(const LossDims& d, int rows_override) {
 // ---- workspace map (floats) -------------------------------------------------------------
 //   Acc [S,N,B,H,W,4]   splat accumulators (sum g*rgb, sum g), one 16-byte unit per pixel
 //   Ovf [S,N,B,H,W,4]   overflow side accumulator (all zero between steps)
-//   Hb  [S,N,B,H,W,8]   backward: per destination pixel (hA[3], sum_c hA*Sp, hB[3], sum_c hB*Sp)
+//   Hb  [2][S,N,B,H,W,4] backward: per destination pixel the two parts (hA[3], sum_c hA*Sp) and (hB[3], sum_c hB*Sp)
 //   G   [S,2,B,H,W,3]   gathered sources 0,1
 //   dG  [S,2,B,H,W,3]   backward: dL/dG_i (gloss = 1)
 //   wavep [n_waves][4]  per-wave partial sums of the stencil kernel

@@ -117,7 +117,8 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   const float* __restrict__ acc = a.Acc + (size_t)it.img * HW * 4;
   const float* __restrict__ ovf = a.flags[it.img] ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;  // wave-uniform
   const float* __restrict__ sp = a.src + (size_t)b * HW * C3 + 3 * i;
-  float* __restrict__ hb = a.Hb + (size_t)it.img * HW * 8;
+  float* __restrict__ hb = a.Hb + (size_t)it.img * HW * 4;  // part A; part B one plane further
+  const size_t hb_plane = (size_t)d.S * d.N * d.B * HW * 4;
   const float nx = (float)(min(gx + 1, d.W - 1) - max(gx - 1, 0) + 1);
   constexpr int HAL = GRAD ? 2 : 1;
   const int r_first = y0 - HAL, r_last = y1 - 1 + HAL;
@@ -228,9 +229,9 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
           wA += hA[ch] * xv;
           wB += hB[ch] * xv;
         }
-        float4* o = reinterpret_cast<float4*>(hb + ((size_t)p * d.W + gx) * 8);
-        o[0] = make_float4(hA[0], hA[1], hA[2], wA);
-        o[1] = make_float4(hB[0], hB[1], hB[2], wB);
+        float* o = hb + ((size_t)p * d.W + gx) * 4;
+        *reinterpret_cast<float4*>(o) = make_float4(hA[0], hA[1], hA[2], wA);
+        *reinterpret_cast<float4*>(o + hb_plane) = make_float4(hB[0], hB[1], hB[2], wB);
       }
     }
   };
