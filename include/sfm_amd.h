@@ -132,6 +132,22 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
                       const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
                       float* d_pose, void* stream);
 
+/* ---- ASPP dilated 3x3 convolutions: nets.py:451-471 (disp_bottleneck_dense) --------------------
+ * slim.conv2d(x, Cout, [3, 3], rate=rate) of nets.py:457, 458, 463 - the convolution itself,
+ * without the arg-scope's batch norm / ELU - as fp32-input MFMA implicit GEMM, and its two
+ * gradients (TF autodiff; implicit in SfMLearner_uni.py:306).  in [B,H,W,Cin] NHWC, w [3,3,Cin,Cout]
+ * HWIO, out [B,H,W,Cout]; SAME padding, stride 1; Cin and Cout multiples of 32.
+ * ws: scratch of sfm_aspp_conv3x3_workspace_floats(B,H,W,Cin,Cout) floats (split-K slabs, flipped
+ * weights), 16-byte aligned, contents undefined between calls; calls sharing it must be stream-ordered.
+ * Results are bitwise reproducible (no atomics). */
+long long sfm_aspp_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int sfm_aspp_conv3x3_fwd(const float* in, const float* w, int B, int H, int W, int Cin, int Cout, int rate,
+                         float* out, float* ws, void* stream);
+int sfm_aspp_conv3x3_bwd_data(const float* gout, const float* w, int B, int H, int W, int Cin, int Cout, int rate,
+                              float* gin, float* ws, void* stream);
+int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, int rate,
+                                float* gw, float* ws, void* stream);
+
 /* ---- measurement aid (no counterpart in the reference; used by bench.py only) -----------
  * When enabled, sfm_loss_forward / sfm_loss_backward bracket each of their launches with
  * HIP events on the caller's stream; sfm_prof_read adds the last step's elapsed ms per stage

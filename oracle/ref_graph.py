@@ -494,6 +494,19 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
 
 
 # ----------------------------------------------------------------------------
+# ASPP dilated convolution
+# ----------------------------------------------------------------------------
+def dilated_conv3x3(x_nhwc: Tensor, w_hwio: Tensor, rate: int) -> Tensor:
+    """``slim.conv2d(x, Cout, [3, 3], rate=rate)`` of ``disp_bottleneck_dense`` (nets.py:457, 458, 463)
+    without the arg-scope's normaliser / activation (nets.py:653-656): NHWC x HWIO, stride 1, SAME
+    padding.  For a 3x3 kernel with dilation ``rate`` TF's SAME pads ``rate`` zero pixels on every
+    side (effective kernel 2*rate + 1, stride 1).                                      ASSUMPTION"""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    w = w_hwio.permute(3, 2, 0, 1)
+    return F.conv2d(x, w, padding=rate, dilation=rate).permute(0, 2, 3, 1).contiguous()
+
+
+# ----------------------------------------------------------------------------
 # data-parallel decomposition of the pixel loss (SURVEY.md section 8e)
 # ----------------------------------------------------------------------------
 def loss_partials(tgt_image, src_image_stack, intrinsics, pred_depth, pred_poses, pred_exp_logits,

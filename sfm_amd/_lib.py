@@ -41,6 +41,10 @@ SIGNATURES = {
     "sfm_loss_num_partials": [_I, _I, _I, _I, _I],
     "sfm_loss_workspace_init": [_P, _I, _I, _I, _I, _I, _P],
     "sfm_loss_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
+    "sfm_aspp_conv3x3_workspace_floats": [_I, _I, _I, _I, _I],
+    "sfm_aspp_conv3x3_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_aspp_conv3x3_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_aspp_conv3x3_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_prof_enable": [_I],
     "sfm_prof_stages": [],
     "sfm_prof_read": [_P],
@@ -65,7 +69,7 @@ def load() -> ctypes.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the build is stale
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name == "sfm_loss_workspace_floats" else ctypes.c_int
+            fn.restype = ctypes.c_longlong if name.endswith("_workspace_floats") else ctypes.c_int
         _lib = lib
     return _lib
 

@@ -1,0 +1,400 @@
+// Dilated 3x3 convolutions of the ASPP decoder (nets.py:451-471 `disp_bottleneck_dense`, the
+// `slim.conv2d(x, out_channels, [3, 3], rate=r)` calls at :457, :458, :463; called five times from
+// `disp_aspp_u_dense`, nets.py:675-686) as fp32-input MFMA implicit GEMMs - the only dense
+// contraction of the hot path.  NHWC activations, HWIO weights,
+// SAME padding (= `rate` zero pixels on every side), stride 1, fp32 in / fp32 accumulate:
+// v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain, so the result differs from the
+// reference's fp32 convolution only by summation order.
+//
+//   forward          out[p, co]  = sum_{tap, ci} in[p + off(tap), ci] * w[tap, ci, co]         M = B*H*W, N = Cout, K = 9*Cin
+//   backward data    gin[p, ci]  = sum_{tap, co} gout[p - off(tap), co] * w[tap, ci, co]       the forward kernel on flipped,
+//                                                                                              transposed weights (Cin <-> Cout)
+//   backward weight  gw[tap, ci, co] = sum_p in[p + off(tap), ci] * gout[p, co]                M = Cin, N = Cout, K = B*H*W per tap
+//
+// One tile core for all three: a workgroup owns a BM x BN output tile, waves own WM x WN sub-tiles
+// made of 32x32 MFMA tiles; per K-step of 32 the A tile is staged in LDS K-major ([k][m], so the
+// MFMA operand read "lane l -> A[m = l & 31][k = l >> 5]" is a conflict-free ds_read_b32) and the B
+// tile as [k][n]; the next step's global loads are issued into registers before the MFMAs of the
+// current one.  The im2col matrix never exists: a tap is a shifted (zero-padded) view of the input.
+// Small-M / small-output problems split K over workgroups (taps for the forward, pixel ranges for
+// the weight gradient) into partial slabs that a second kernel sums in a fixed order: results are
+// bitwise reproducible, no atomics.
+#include "sfm_device.h"
+#include "sfm_internal.h"
+
+namespace sfm {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 32;
+
+// acc[i][j] += A[wm0 + 32 i .. +32][0..BK) * B[0..BK)[wn0 + 32 j .. +32]
+template <int TM, int TN>
+__device__ __forceinline__ void mma_step(const float* __restrict__ As, const float* __restrict__ Bs, int lda, int ldb,
+                                         int wm0, int wn0, f32x16 (&acc)[TM][TN]) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK; kk += 2) {
+    float a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = As[(kk + h) * lda + wm0 + i * 32 + r];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + h) * ldb + wn0 + j * 32 + r];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+template <int TM, int TN>
+__device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], float* __restrict__ out, long ld, long row0,
+                                          long rows, int col0) {
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long row = row0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (row < rows) out[row * ld + col0 + j * 32 + c] = acc[i][j][reg];
+      }
+}
+
+// ------------------------------------------------------------------ forward / backward data
+// grid (ceil(M / BM), Cout / BN, splits); a split covers taps [z * tps, (z + 1) * tps) and writes
+// its own slab out + z * split_stride.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void aspp_conv_kernel(
+    const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out, int B, int H, int W, int Cin,
+    int Cout, int rate, int tps, long split_stride) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int LDA = BM + 1, LDB = BN + 4;
+  constexpr int A_IT = BM * BK / 4 / NT, B_IT = BK * BN / 4 / NT;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(A_IT >= 1 && B_IT >= 1 && (BM * BK / 4) % NT == 0 && (BK * BN / 4) % NT == 0, "tile / thread mismatch");
+  __shared__ float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int wm0 = (wave % (BM / WM)) * WM, wn0 = (wave / (BM / WM)) * WN;
+  const long M = (long)B * H * W;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tap0 = blockIdx.z * tps, tap1 = min(9, tap0 + tps);
+
+  // the A rows this thread stages: row = it * (NT / 8) + tid / 8, channels kc .. kc + 3 of the K-step
+  const int kc = (tid & 7) * 4;
+  int py[A_IT], px[A_IT];
+  long pb[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const long m = m0 + it * (NT / 8) + (tid >> 3);
+    if (m < M) {
+      const long bi = m / ((long)H * W);
+      const int rem = (int)(m - bi * H * W);
+      py[it] = rem / W;
+      px[it] = rem - py[it] * W;
+      pb[it] = bi * H * W;
+    } else {
+      py[it] = px[it] = 0;
+      pb[it] = -1;
+    }
+  }
+  float4 ra[A_IT], rb[B_IT];
+  auto load_tiles = [&](int tap, int c0) {
+    const int dy = (tap / 3 - 1) * rate, dx = (tap % 3 - 1) * rate;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int y = py[it] + dy, x = px[it] + dx;
+      ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pb[it] >= 0 && y >= 0 && y < H && x >= 0 && x < W)
+        ra[it] = *reinterpret_cast<const float4*>(in + (pb[it] + (long)y * W + x) * Cin + c0 + kc);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = it * NT + tid, k = idx / (BN / 4), n4 = idx % (BN / 4);
+      rb[it] = *reinterpret_cast<const float4*>(wt + ((long)tap * Cin + c0 + k) * Cout + n0 + n4 * 4);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int r = it * (NT / 8) + (tid >> 3);
+      As[(kc + 0) * LDA + r] = ra[it].x;
+      As[(kc + 1) * LDA + r] = ra[it].y;
+      As[(kc + 2) * LDA + r] = ra[it].z;
+      As[(kc + 3) * LDA + r] = ra[it].w;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = it * NT + tid, k = idx / (BN / 4), n4 = idx % (BN / 4);
+      *reinterpret_cast<float4*>(&Bs[k * LDB + n4 * 4]) = rb[it];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[i][j][reg] = 0.f;
+
+  const int csteps = Cin / BK, steps = (tap1 - tap0) * csteps;
+  if (steps > 0) load_tiles(tap0, 0);
+  for (int s = 0; s < steps; ++s) {
+    store_tiles();
+    __syncthreads();
+    if (s + 1 < steps) load_tiles(tap0 + (s + 1) / csteps, ((s + 1) % csteps) * BK);
+    mma_step<TM, TN>(As, Bs, LDA, LDB, wm0, wn0, acc);
+    __syncthreads();
+  }
+  store_acc<TM, TN>(acc, out + blockIdx.z * split_stride, Cout, m0 + wm0, M, n0 + wn0);
+}
+
+// ------------------------------------------------------------------ backward weight
+// grid ((Cin / BM) * (Cout / BN), 9, splits); a split covers pixels [z * pps, (z + 1) * pps) and
+// writes its own slab gw + z * 9*Cin*Cout.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
+    const float* __restrict__ in, const float* __restrict__ gout, float* __restrict__ gw, int B, int H, int W, int Cin,
+    int Cout, int rate, long pps) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int A_IT = BK * BM / 4 / NT, B_IT = BK * BN / 4 / NT;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(A_IT >= 1 && B_IT >= 1 && (BK * BM / 4) % NT == 0 && (BK * BN / 4) % NT == 0, "tile / thread mismatch");
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int wm0 = (wave % (BM / WM)) * WM, wn0 = (wave / (BM / WM)) * WN;
+  const int ntn = Cout / BN;
+  const int ci0 = (blockIdx.x / ntn) * BM, co0 = (blockIdx.x % ntn) * BN;
+  const int tap = blockIdx.y;
+  const int dy = (tap / 3 - 1) * rate, dx = (tap % 3 - 1) * rate;
+  const long M = (long)B * H * W;
+  const long p0 = (long)blockIdx.z * pps, p1 = min(M, p0 + pps);
+
+  float4 ra[A_IT], rb[B_IT];
+  auto load_tiles = [&](long pstep) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int idx = it * NT + tid, k = idx / (BM / 4), c4 = idx % (BM / 4);
+      const long p = pstep + k;
+      ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < p1) {
+        const long bi = p / ((long)H * W);
+        const int rem = (int)(p - bi * H * W);
+        const int y = rem / W + dy, x = rem % W + dx;
+        if (y >= 0 && y < H && x >= 0 && x < W)
+          ra[it] = *reinterpret_cast<const float4*>(in + (bi * H * W + (long)y * W + x) * Cin + ci0 + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = it * NT + tid, k = idx / (BN / 4), n4 = idx % (BN / 4);
+      const long p = pstep + k;
+      rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < p1) rb[it] = *reinterpret_cast<const float4*>(gout + p * Cout + co0 + n4 * 4);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int idx = it * NT + tid, k = idx / (BM / 4), c4 = idx % (BM / 4);
+      *reinterpret_cast<float4*>(&As[k * LDA + c4 * 4]) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = it * NT + tid, k = idx / (BN / 4), n4 = idx % (BN / 4);
+      *reinterpret_cast<float4*>(&Bs[k * LDB + n4 * 4]) = rb[it];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[i][j][reg] = 0.f;
+
+  if (p0 < p1) load_tiles(p0);
+  for (long ps = p0; ps < p1; ps += BK) {
+    store_tiles();
+    __syncthreads();
+    if (ps + BK < p1) load_tiles(ps + BK);
+    mma_step<TM, TN>(As, Bs, LDA, LDB, wm0, wn0, acc);
+    __syncthreads();
+  }
+  float* o = gw + ((long)blockIdx.z * 9 + tap) * Cin * Cout;
+  store_acc<TM, TN>(acc, o, Cout, ci0 + wm0, Cin, co0 + wn0);
+}
+
+// out[e] = sum_z part[z][e], z ascending (fixed order)
+__global__ __launch_bounds__(kBlock) void aspp_reduce_kernel(const float* __restrict__ part, long n4, int splits,
+                                                             float* __restrict__ out) {
+  const long e = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n4) return;
+  float4 s = reinterpret_cast<const float4*>(part)[e];
+  for (int z = 1; z < splits; ++z) {
+    const float4 v = reinterpret_cast<const float4*>(part)[(long)z * n4 + e];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[e] = s;
+}
+
+// wt[t][co][ci] = w[8 - t][ci][co]: the backward-data problem as a forward convolution
+__global__ __launch_bounds__(kBlock) void aspp_flip_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                                           float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((long)(8 - t) * Cin + ci0 + r) * Cout + co0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) wt[((long)t * Cout + co0 + r) * Cin + ci0 + tx] = tile[tx][r];
+}
+
+struct ConvPlan {
+  int cfg;      // 0: 128x128, 1: 256x64, 2: 256x32
+  int bm, bn;
+  int splits;   // over taps
+  int tps;      // taps per split
+};
+
+static ConvPlan conv_plan(long M, int Cout) {
+  ConvPlan p;
+  if (Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
+  else if (Cout % 64 == 0) { p.cfg = 1; p.bm = 256; p.bn = 64; }
+  else { p.cfg = 2; p.bm = 256; p.bn = 32; }
+  const long blocks = ((M + p.bm - 1) / p.bm) * (Cout / p.bn);
+  p.splits = blocks >= 256 ? 1 : (blocks * 3 >= 256 ? 3 : 9);
+  p.tps = 9 / p.splits;
+  return p;
+}
+
+struct WgradPlan {
+  int cfg;  // 0: 128x128, 1: 128x64, 2: 64x32, 3: 32x32
+  int bm, bn;
+  int splits;
+  long pps;  // pixels per split, multiple of BK
+};
+
+static WgradPlan wgrad_plan(long M, int Cin, int Cout) {
+  WgradPlan p;
+  if (Cin % 128 == 0 && Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
+  else if (Cin % 128 == 0 && Cout % 64 == 0) { p.cfg = 1; p.bm = 128; p.bn = 64; }
+  else if (Cin % 64 == 0) { p.cfg = 2; p.bm = 64; p.bn = 32; }
+  else { p.cfg = 3; p.bm = 32; p.bn = 32; }
+  const long base = (long)(Cin / p.bm) * (Cout / p.bn) * 9;
+  long splits = (512 + base - 1) / base;
+  const long max_splits = (M + 8 * BK - 1) / (8 * BK);  // at least 8 K-steps per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 256) splits = 256;
+  if (splits < 1) splits = 1;
+  p.pps = ((M + splits - 1) / splits + BK - 1) / BK * BK;
+  p.splits = (int)((M + p.pps - 1) / p.pps);
+  return p;
+}
+
+static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
+  return B > 0 && H > 0 && W > 0 && rate > 0 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0 &&
+         (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 40);
+}
+
+static int launch_conv(const float* in, const float* wt, float* out, float* slabs, int B, int H, int W, int Cin, int Cout,
+                       int rate, hipStream_t stream) {
+  const long M = (long)B * H * W;
+  const ConvPlan p = conv_plan(M, Cout);
+  float* dst = p.splits > 1 ? slabs : out;
+  const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), Cout / p.bn, p.splits);
+  const long stride = M * Cout;
+  if (p.cfg == 0)
+    hipLaunchKernelGGL((aspp_conv_kernel<128, 128, 64, 64>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, rate,
+                       p.tps, stride);
+  else if (p.cfg == 1)
+    hipLaunchKernelGGL((aspp_conv_kernel<256, 64, 64, 64>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, rate,
+                       p.tps, stride);
+  else
+    hipLaunchKernelGGL((aspp_conv_kernel<256, 32, 64, 32>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, rate,
+                       p.tps, stride);
+  if (p.splits > 1) {
+    const long n4 = stride / 4;
+    hipLaunchKernelGGL(aspp_reduce_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, slabs, n4,
+                       p.splits, out);
+  }
+  return sfm_last_error();
+}
+
+}  // namespace
+
+}  // namespace sfm
+
+using namespace sfm;
+
+// Workspace (floats) shared by the three calls below for one layer shape: the larger of the
+// split-K slabs of the forward / backward-data problems plus the flipped weights, and the slabs of
+// the weight gradient.
+extern "C" long long sfm_aspp_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout) {
+  if (!conv_dims_ok(B, H, W, Cin, Cout, 1)) return SFM_ERR_ARG;
+  const long M = (long)B * H * W;
+  const ConvPlan f = conv_plan(M, Cout), d = conv_plan(M, Cin);
+  const WgradPlan g = wgrad_plan(M, Cin, Cout);
+  const long fwd = f.splits > 1 ? (long)f.splits * M * Cout : 0;
+  const long bwd = (d.splits > 1 ? (long)d.splits * M * Cin : 0) + 9L * Cin * Cout;
+  const long wg = g.splits > 1 ? (long)g.splits * 9 * Cin * Cout : 0;
+  long n = fwd > bwd ? fwd : bwd;
+  if (wg > n) n = wg;
+  return n + 4;
+}
+
+// slim.conv2d(in, Cout, [3, 3], rate=rate) without its normaliser / activation (nets.py:457):
+// in [B,H,W,Cin], w [3,3,Cin,Cout] (HWIO), out [B,H,W,Cout].
+extern "C" int sfm_aspp_conv3x3_fwd(const float* in, const float* w, int B, int H, int W, int Cin, int Cout, int rate,
+                                    float* out, float* ws, void* stream) {
+  if (!in || !w || !out || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
+  return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, rate, (hipStream_t)stream);
+}
+
+// dL/d in [B,H,W,Cin] from gout = dL/d out [B,H,W,Cout] (TF autodiff of the same call).
+extern "C" int sfm_aspp_conv3x3_bwd_data(const float* gout, const float* w, int B, int H, int W, int Cin, int Cout,
+                                         int rate, float* gin, float* ws, void* stream_) {
+  if (!gout || !w || !gin || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* wt = ws;  // [9][Cout][Cin]
+  hipLaunchKernelGGL(aspp_flip_kernel, dim3(Cin / 32, Cout / 32, 9), dim3(kBlock), 0, stream, w, Cin, Cout, wt);
+  const long wsz = (9L * Cin * Cout + 3) & ~3L;
+  return launch_conv(gout, wt, gin, ws + wsz, B, H, W, Cout, Cin, rate, stream);
+}
+
+// dL/d w [3,3,Cin,Cout].
+extern "C" int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout,
+                                           int rate, float* gw, float* ws, void* stream_) {
+  if (!in || !gout || !gw || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const long M = (long)B * H * W;
+  const WgradPlan p = wgrad_plan(M, Cin, Cout);
+  float* dst = p.splits > 1 ? ws : gw;
+  const dim3 grid((Cin / p.bm) * (Cout / p.bn), 9, p.splits);
+  if (p.cfg == 0)
+    hipLaunchKernelGGL((aspp_wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
+                       rate, p.pps);
+  else if (p.cfg == 1)
+    hipLaunchKernelGGL((aspp_wgrad_kernel<128, 64, 64, 32>), grid, dim3(256), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
+                       rate, p.pps);
+  else if (p.cfg == 2)
+    hipLaunchKernelGGL((aspp_wgrad_kernel<64, 32, 32, 32>), grid, dim3(128), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
+                       rate, p.pps);
+  else
+    hipLaunchKernelGGL((aspp_wgrad_kernel<32, 32, 32, 32>), grid, dim3(64), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
+                       rate, p.pps);
+  if (p.splits > 1) {
+    const long n4 = 9L * Cin * Cout / 4;
+    hipLaunchKernelGGL(aspp_reduce_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws, n4,
+                       p.splits, gw);
+  }
+  return sfm_last_error();
+}

@@ -1,0 +1,81 @@
+"""GPU parity of the ASPP dilated 3x3 convolutions (csrc/aspp.hip, fp32-input MFMA implicit GEMM)
+against the oracle (oracle.ref_graph.dilated_conv3x3 = nets.py:457 restated with torch-CPU conv2d)
+and torch autograd for the two gradients.  fp32 in / fp32 accumulate: tolerance 1e-5 relative
+(summation order only; K up to 9216)."""
+import pytest
+import torch
+
+import sfm_amd
+from oracle import ref_graph as R
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+CASES = [  # (B, H, W, Cin, Cout, rate): every tile configuration, ragged M, rates beyond the image
+    (1, 5, 7, 32, 32, 1),
+    (2, 9, 13, 64, 32, 2),      # last-level shape class (64 -> 32), split weight gradient
+    (1, 8, 26, 128, 64, 3),     # 128 -> 64
+    (2, 8, 26, 256, 128, 4),    # 128-wide tiles, tap-split forward
+    (1, 6, 6, 96, 160, 12),     # odd multiples of 32, rate larger than the image
+    (1, 16, 52, 64, 64, 6),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,rate", CASES)
+def test_dilated_conv_forward_and_gradients(dev, B, H, W, Cin, Cout, rate):
+    g = torch.Generator().manual_seed(100 + Cin + Cout + rate)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / (3.0 * Cin ** 0.5)
+    go = torch.randn(B, H, W, Cout, generator=g)
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo = R.dilated_conv3x3(xo, wo, rate)
+    yo.backward(go)
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    yg = sfm_amd.dilated_conv3x3(xg, wg, rate)
+    yg.backward(go.to(dev))
+    assert rel_err(yg, yo) <= TOL
+    assert rel_err(xg.grad, xo.grad) <= TOL
+    assert rel_err(wg.grad, wo.grad) <= TOL
+
+
+def test_identity_tap_and_shift_known_answer(dev):
+    """w = identity on the centre tap returns the input; identity on tap (0, 0) returns the input shifted
+    by (-rate, -rate) with zero fill - catches transposed / mirrored tile maps (asymmetric)."""
+    B, H, W, C, rate = 1, 12, 20, 64, 3
+    x = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(7)).to(dev)
+    eye = torch.eye(C)
+    w = torch.zeros(3, 3, C, C); w[1, 1] = eye
+    assert torch.equal(sfm_amd.dilated_conv3x3(x, w.to(dev), rate), x)
+    w = torch.zeros(3, 3, C, C); w[0, 2] = eye   # tap dy = -1, dx = +1
+    y = sfm_amd.dilated_conv3x3(x, w.to(dev), rate)
+    ref = torch.zeros_like(x)
+    ref[:, rate:, :W - rate] = x[:, :H - rate, rate:]
+    assert torch.equal(y, ref)
+
+
+def test_bitwise_reproducible(dev):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 26, 256, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(3, 3, 256, 128, generator=g) / 48).to(dev).requires_grad_(True)
+    outs = []
+    for _ in range(2):
+        x.grad = w.grad = None
+        y = sfm_amd.dilated_conv3x3(x, w, 2)
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("h,w_,Cin,Cout,rate", [(8, 26, 1024, 512, 2), (128, 416, 64, 32, 12)],
+                         ids=["concat 8x26 1024->512 r2", "concat4 128x416 64->32 r12"])
+def test_full_size_layers_of_config5(dev, h, w_, Cin, Cout, rate):
+    """The smallest-M and the largest-M layer of BASELINE.json configs[4] (B=8), forward against the oracle."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, h, w_, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / (3.0 * Cin ** 0.5)
+    torch.set_num_threads(16)
+    yo = R.dilated_conv3x3(x, w, rate)
+    yg = sfm_amd.dilated_conv3x3(x.to(dev), w.to(dev), rate)
+    assert rel_err(yg, yo) <= TOL
