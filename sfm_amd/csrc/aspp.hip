@@ -178,20 +178,31 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
   const long M = (long)B * H * W;
   const long p0 = (long)blockIdx.z * pps, p1 = min(M, p0 + pps);
 
+  // pixel coordinates of the A rows this thread stages, advanced by BK pixels per K-step (no divisions
+  // in the loop).  Row k of the step = it * (NT / (BM / 4)) + tid / (BM / 4).
+  int ay[A_IT], ax[A_IT];
+  long ab[A_IT];  // b * H * W
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const long p = p0 + (it * NT + tid) / (BM / 4);
+    const long bi = p / ((long)H * W);
+    const int rem = (int)(p - bi * H * W);
+    ay[it] = rem / W;
+    ax[it] = rem - ay[it] * W;
+    ab[it] = bi * H * W;
+  }
   float4 ra[A_IT], rb[B_IT];
   auto load_tiles = [&](long pstep) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int idx = it * NT + tid, k = idx / (BM / 4), c4 = idx % (BM / 4);
-      const long p = pstep + k;
       ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < p1) {
-        const long bi = p / ((long)H * W);
-        const int rem = (int)(p - bi * H * W);
-        const int y = rem / W + dy, x = rem % W + dx;
-        if (y >= 0 && y < H && x >= 0 && x < W)
-          ra[it] = *reinterpret_cast<const float4*>(in + (bi * H * W + (long)y * W + x) * Cin + ci0 + c4 * 4);
-      }
+      const int y = ay[it] + dy, x = ax[it] + dx;
+      if (pstep + k < p1 && y >= 0 && y < H && x >= 0 && x < W)
+        ra[it] = *reinterpret_cast<const float4*>(in + (ab[it] + (long)y * W + x) * Cin + ci0 + c4 * 4);
+      ax[it] += BK;  // next K-step
+      while (ax[it] >= W) { ax[it] -= W; ++ay[it]; }
+      while (ay[it] >= H) { ay[it] -= H; ab[it] += (long)H * W; }
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
@@ -265,13 +276,24 @@ struct ConvPlan {
   int tps;      // taps per split
 };
 
-static ConvPlan conv_plan(long M, int Cout) {
+static ConvPlan conv_plan(long M, int Cin, int Cout) {
   ConvPlan p;
   if (Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
   else if (Cout % 64 == 0) { p.cfg = 1; p.bm = 256; p.bn = 64; }
   else { p.cfg = 2; p.bm = 256; p.bn = 32; }
-  const long blocks = ((M + p.bm - 1) / p.bm) * (Cout / p.bn);
-  p.splits = blocks >= 256 ? 1 : (blocks * 3 >= 256 ? 3 : 9);
+  // taps per workgroup.  Model: the fullest CU gets n = ceil(base * splits / 256) workgroups of 9 / splits
+  // taps; up to 3 are co-resident and overlap each other's stalls (measured: one workgroup alone on a CU
+  // runs at ~0.66 of the rate three reach).  A split also writes and re-reads `splits` M x N slabs (~4 TB/s).
+  const long base = ((M + p.bm - 1) / p.bm) * (Cout / p.bn);
+  const double t_tap = 2.0 * p.bm * p.bn * (double)Cin / (0.6 * 157.3e12 / 256.0);
+  double best = 1e30;
+  p.splits = 1;
+  for (int sp : {1, 3, 9}) {
+    const long n = (base * sp + 255) / 256;
+    const double eff = n >= 3 ? 1.0 : (n == 2 ? 0.9 : 0.66);
+    const double t = (double)n * (9 / sp) * t_tap / eff + (sp > 1 ? 2.0 * sp * (double)M * Cout * 4.0 / 4.0e12 : 0.0);
+    if (t < best * 0.97) { best = t; p.splits = sp; }
+  }
   p.tps = 9 / p.splits;
   return p;
 }
@@ -308,7 +330,7 @@ static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
 static int launch_conv(const float* in, const float* wt, float* out, float* slabs, int B, int H, int W, int Cin, int Cout,
                        int rate, hipStream_t stream) {
   const long M = (long)B * H * W;
-  const ConvPlan p = conv_plan(M, Cout);
+  const ConvPlan p = conv_plan(M, Cin, Cout);
   float* dst = p.splits > 1 ? slabs : out;
   const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), Cout / p.bn, p.splits);
   const long stride = M * Cout;
@@ -341,7 +363,7 @@ using namespace sfm;
 extern "C" long long sfm_aspp_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout) {
   if (!conv_dims_ok(B, H, W, Cin, Cout, 1)) return SFM_ERR_ARG;
   const long M = (long)B * H * W;
-  const ConvPlan f = conv_plan(M, Cout), d = conv_plan(M, Cin);
+  const ConvPlan f = conv_plan(M, Cin, Cout), d = conv_plan(M, Cout, Cin);
   const WgradPlan g = wgrad_plan(M, Cin, Cout);
   const long fwd = f.splits > 1 ? (long)f.splits * M * Cout : 0;
   const long bwd = (d.splits > 1 ? (long)d.splits * M * Cin : 0) + 9L * Cin * Cout;
