@@ -80,12 +80,58 @@ def cpu_baseline(seed: int) -> dict:
                       f"(PyTorch-CPU restatement; TensorFlow is not installable here)"}
 
 
+ASPP_LAYERS = [  # (h, w, Cin, Cout, rates) of disp_aspp_u_dense at 416x128 (nets.py:675-686)
+    (8, 26, 1024, 512, (2, 4)), (16, 52, 512, 256, (2, 4)), (32, 104, 256, 128, (2, 4)),
+    (64, 208, 128, 64, (3, 6)), (128, 416, 64, 32, (3, 6, 12))]
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+
+
+def aspp_leg(dev, reps: int = 5) -> dict:
+    """configs[4]: the 11 dilated 3x3 convolutions of the ASPP decoder at B=8, forward + backward data +
+    backward weight through the C ABI, timed with events on the launch stream."""
+    from sfm_amd import _lib
+    from sfm_amd._lib import call, ptr, stream_of
+    lib = _lib.load()
+    jobs, flops = [], 0.0
+    for h, w_, ci, co, rates in ASPP_LAYERS:
+        x = torch.randn(B, h, w_, ci, device=dev)
+        wt = torch.randn(3, 3, ci, co, device=dev) / (3 * ci ** 0.5)
+        go = torch.randn(B, h, w_, co, device=dev)
+        y, gx, gw = torch.empty_like(go), torch.empty_like(x), torch.empty_like(wt)
+        ws = torch.empty(lib.sfm_aspp_conv3x3_workspace_floats(B, h, w_, ci, co), device=dev)
+        for r in rates:
+            jobs.append((x, wt, go, y, gx, gw, ws, h, w_, ci, co, r))
+            flops += 3 * 2.0 * B * h * w_ * co * 9 * ci
+
+    def run():
+        for x, wt, go, y, gx, gw, ws, h, w_, ci, co, r in jobs:
+            st = stream_of(x)
+            call("sfm_aspp_conv3x3_fwd", ptr(x), ptr(wt), B, h, w_, ci, co, r, ptr(y), ptr(ws), st)
+            call("sfm_aspp_conv3x3_bwd_data", ptr(go), ptr(wt), B, h, w_, ci, co, r, ptr(gx), ptr(ws), st)
+            call("sfm_aspp_conv3x3_bwd_weight", ptr(x), ptr(go), B, h, w_, ci, co, r, ptr(gw), ptr(ws), st)
+
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"workload": "11 dilated 3x3 convs of disp_aspp_u_dense, B=8 416x128, fwd + bwd-data + bwd-weight (configs[4])",
+            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+            "ms": ms, "flops": flops, "dtype": "f32"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aspp", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,6 +220,9 @@ def main() -> None:
                          "stage_us": per_stage_us,
                          "step_frac_of_hbm_peak": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if world == 1 and not args.no_aspp:
+            line["aspp"] = aspp_leg(dev)
+            line["config"]["config5_step_ms"] = ms_step + line["aspp"]["ms"]  # ASPP convs + warp loss, fwd + bwd
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth.SEED)
         print(json.dumps(line), flush=True)

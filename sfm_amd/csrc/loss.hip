@@ -110,13 +110,13 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
   shift[k] = o;
 }
 
-// grid (tiles_x, tiles_y, S*N*B), 256 threads.
+// grid: tiles_x * tiles_y * S*N*B blocks (1-D), 256 threads.
 __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __restrict__ tgt,
                                                                  const float* __restrict__ src,
                                                                  const float* __restrict__ depth,
                                                                  const float* __restrict__ trans,
                                                                  const float* __restrict__ params, LossDims d,
-                                                                 float step_x, float step_y,
+                                                                 float step_x, float step_y, int tiles_x, int tiles_y,
                                                                  const int4* __restrict__ shift, float* __restrict__ G,
                                                                  float* __restrict__ Acc, float* __restrict__ Ovf,
                                                                  int* __restrict__ flags) {
@@ -126,12 +126,14 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
   // the float -> double conversion is exact and the sums lose nothing before the final rounding.
   __shared__ double acc[4 * TP];
   __shared__ int4 tcache[kCacheW * kCacheH];
-  const int tx = blockIdx.x, ty = blockIdx.y, tiles_x = gridDim.x;
-  const int img = blockIdx.z;  // (s*N + i)*B + b
+  // 1-D grid in XCD-contiguous order: neighbouring tiles (overlapping scan windows) share an L2
+  const int blk = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y;
+  const int img = blk / (tiles_x * tiles_y);  // (s*N + i)*B + b
   const int b = img % d.B, si = img / d.B, i = si % d.N, s = si / d.N;
   const int HW = d.H * d.W, C3 = 3 * d.N;
   const int ng = d.N < 2 ? d.N : 2;
-  const int4* __restrict__ stab = shift + (size_t)img * (gridDim.x * gridDim.y);
+  const int4* __restrict__ stab = shift + (size_t)img * (tiles_x * tiles_y);
   const int4 mine = stab[ty * tiles_x + tx];
   const int x0 = tx * STW, y0 = ty * STH;
   const int x1 = min(x0 + STW, d.W), y1 = min(y0 + STH, d.H);
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
   const int cty0 = min(max(y0 + STH / 2 + mine.y, 0), d.H - 1) / STH - kCacheTY;
   if (threadIdx.x < kCacheW * kCacheH) {
     const int cx_ = ctx0 + (int)threadIdx.x % kCacheW, cy_ = cty0 + (int)threadIdx.x / kCacheW;
-    if (cx_ >= 0 && cx_ < tiles_x && cy_ >= 0 && cy_ < (int)gridDim.y)
+    if (cx_ >= 0 && cx_ < tiles_x && cy_ >= 0 && cy_ < tiles_y)
       tcache[threadIdx.x] = scan_rect(cx_, cy_, stab[cy_ * tiles_x + cx_]);
   }
   __syncthreads();
@@ -322,8 +324,14 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
 }
 
 // ------------------------------------------------------------------ fused warp backward
-// grid (blocks, B, S).  d_depth [S,B,H,W], d_trans [S,B,H,W,3N], dP partials
-// [S][N*B][nblk][12].
+// One workgroup = one STW x STH pixel tile of one (scale, batch item): 2-D tiles keep the footprint of
+// the corner gathers (Hb, source taps) close to the tile itself, and the XCD-contiguous block order
+// (sfm_device.h) puts neighbouring tiles behind the same L2, so their overlapping halos are fetched
+// from HBM once.  A thread owns kLossPPT pixels; per pixel it walks the N sources (compile-time N: the
+// dL/dP accumulators of every source stay in registers, d_depth is summed in a register and the
+// 12-byte d_trans pieces of all sources are stored back to back, so each 128-byte line leaves L2 once).
+// grid: S*B*tiles blocks (1-D).  d_depth [S,B,H,W], d_trans [S,B,H,W,3N], dP partials [S][N*B][tiles][12].
+template <int N>
 __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                const float* __restrict__ src,
                                                                const float* __restrict__ depth,
@@ -332,84 +340,93 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
                                                                const float* __restrict__ Hb,
                                                                const float* __restrict__ dG,
                                                                const float* __restrict__ coef, LossDims d, float step_x,
-                                                               float step_y, float* __restrict__ d_depth,
+                                                               float step_y, int tiles_x, int tiles_y,
+                                                               float* __restrict__ d_depth,
                                                                float* __restrict__ d_trans,
                                                                float* __restrict__ dPp, float* __restrict__ Ovf,
                                                                const int* __restrict__ flags) {
   __shared__ float red[4 * 12];
-  const int b = blockIdx.y, s = blockIdx.z;
-  const int HW = d.H * d.W, C3 = 3 * d.N;
-  const int ng = d.N < 2 ? d.N : 2;
+  constexpr int C3 = 3 * N, NG = N < 2 ? N : 2;
+  const int ntile = tiles_x * tiles_y;
+  const int blk = xcd_contiguous(blockIdx.x, gridDim.x);  // (s*B + b)*ntile + tile
+  const int tile = blk % ntile, sbi = blk / ntile, b = sbi % d.B, s = sbi / d.B;
+  const int x0 = (tile % tiles_x) * STW, y0 = (tile / tiles_x) * STH;
+  const int HW = d.H * d.W;
   const size_t img = (size_t)b * HW;
   const size_t sb = ((size_t)s * d.B + b) * HW;
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
   const float gl = coef[0];  // dL/d loss
-  const size_t hb_plane = (size_t)d.S * d.N * d.B * HW * 4;
-  float ddsum[kLossPPT];
+  const size_t hb_plane = (size_t)d.S * N * d.B * HW * 4;
+  Pose ps[N];
+  float kv[N], dp[N][12];
+  bool clr[N];
 #pragma unroll
-  for (int it = 0; it < kLossPPT; ++it) ddsum[it] = 0.0f;
-  for (int i = 0; i < d.N; ++i) {
-    const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-    const float* hb = Hb + (((size_t)s * d.N + i) * d.B + b) * HW * 4;  // part A; part B one plane further
-    const float kv = coef[1 + s * d.N + i];  // gloss * kV(s, i)
-    // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
-    float4* ovz = flags[(s * d.N + i) * d.B + b]
-                      ? reinterpret_cast<float4*>(Ovf + (((size_t)s * d.N + i) * d.B + b) * HW * 4) : nullptr;
-    float dp[12];
+  for (int i = 0; i < N; ++i) {
+    ps[i] = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
+    kv[i] = coef[1 + s * N + i];  // gloss * kV(s, i)
+    clr[i] = flags[(s * N + i) * d.B + b] != 0;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) dp[k] = 0.0f;
+    for (int k = 0; k < 12; ++k) dp[i][k] = 0.0f;
+  }
+#pragma unroll 1
+  for (int it = 0; it < kLossPPT; ++it) {
+    const int k = it * kBlock + threadIdx.x;
+    const int u = x0 + (k & (STW - 1)), v = y0 + k / STW;
+    if (u >= d.W || v >= d.H) continue;
+    const int p = v * d.W + u;
+    const float dep = depth[sb + p];
+    const f3 tv = ld3(tgt + (img + p) * 3);
+    const float gxc = grid_coord(u, step_x, xmax), gyc = grid_coord(v, step_y, ymax);
+    float ddsum = 0.0f;
+    float dts[C3];
 #pragma unroll
-    for (int it = 0; it < kLossPPT; ++it) {
-      const int p = (blockIdx.x * kLossPPT + it) * kBlock + threadIdx.x;
-      if (p < HW) {
-        if (ovz) ovz[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int v = p / d.W, u = p - v * d.W;
-        const float dep = depth[sb + p];
-        const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
-        const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, true, t.x, t.y, t.z);
-        const Corners c = corners(g.x, g.y, xmax, ymax);
-        const int i00 = c.y0 * d.W + c.x0, i01 = c.y1 * d.W + c.x0, i10 = c.y0 * d.W + c.x1, i11 = c.y1 * d.W + c.x1;
-        float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
-        if (i < ng) {
-          const float wx0 = c.fx1 - g.x, wx1 = g.x - c.fx0, wy0 = c.fy1 - g.y, wy1 = g.y - c.fy0;
-          const float* sbase = src + img * C3 + 3 * i;
-          const f3 a = ld3(sbase + (size_t)i00 * C3), bb = ld3(sbase + (size_t)i01 * C3);
-          const f3 cc = ld3(sbase + (size_t)i10 * C3), dd = ld3(sbase + (size_t)i11 * C3);
-          const f3 go = ld3(dG + ((((size_t)s * ng + i) * d.B + b) * HW + p) * 3);
-          gx_ = gl * (go.x * (wy0 * (cc.x - a.x) + wy1 * (dd.x - bb.x)) + go.y * (wy0 * (cc.y - a.y) + wy1 * (dd.y - bb.y)) +
-                      go.z * (wy0 * (cc.z - a.z) + wy1 * (dd.z - bb.z)));
-          gy_ = gl * (go.x * (wx0 * (bb.x - a.x) + wx1 * (dd.x - cc.x)) + go.y * (wx0 * (bb.y - a.y) + wx1 * (dd.y - cc.y)) +
-                      go.z * (wx0 * (bb.z - a.z) + wx1 * (dd.z - cc.z)));
-        }
-        const SplatW sw = splat_weights(g.x, g.y, c, true, g.z);
-        const f3 tv = ld3(tgt + (img + p) * 3);
-        const int idx[4] = {i00, i01, i10, i11};
-        float dgk[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 ha = *reinterpret_cast<const float4*>(hb + (size_t)idx[k] * 4);
-          const float4 hv = *reinterpret_cast<const float4*>(hb + hb_plane + (size_t)idx[k] * 4);
-          const float da = ((ha.x * tv.x + ha.y * tv.y) + ha.z * tv.z) - ha.w;
-          const float dv = ((hv.x * tv.x + hv.y * tv.y) + hv.z * tv.z) - hv.w;
-          dgk[k] = (gl * da + kv * dv) * sw.g[k];
-        }
-        gx_ += -(dgk[0] + dgk[1]) * sw.dx0 + (dgk[2] + dgk[3]) * sw.dx1;
-        gy_ += -(dgk[0] + dgk[2]) * sw.dy0 + (dgk[1] + dgk[3]) * sw.dy1;
-        gz_ = -0.25f * sw.zin * ((dgk[0] + dgk[1]) + (dgk[2] + dgk[3]));
-        float dd_, dt0, dt1, dt2;
-        geom_bwd(ps, g, dep, true, t.x, t.y, t.z, gx_, gy_, gz_, dd_, dt0, dt1, dt2, dp);
-        ddsum[it] += dd_;
-        st3(d_trans + (sb + p) * C3 + 3 * i, dt0, dt1, dt2);
+    for (int i = 0; i < N; ++i) {
+      const size_t simg = ((size_t)s * N + i) * d.B + b;
+      // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
+      if (clr[i]) reinterpret_cast<float4*>(Ovf + simg * HW * 4)[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* hb = Hb + simg * HW * 4;  // part A; part B one plane further
+      const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
+      const Geom g = geom_fwd(ps[i], gxc, gyc, dep, true, t.x, t.y, t.z);
+      const Corners c = corners(g.x, g.y, xmax, ymax);
+      const int i00 = c.y0 * d.W + c.x0, i01 = c.y1 * d.W + c.x0, i10 = c.y0 * d.W + c.x1, i11 = c.y1 * d.W + c.x1;
+      float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
+      if (i < NG) {
+        const float wx0 = c.fx1 - g.x, wx1 = g.x - c.fx0, wy0 = c.fy1 - g.y, wy1 = g.y - c.fy0;
+        const float* sbase = src + img * C3 + 3 * i;
+        const f3 a = ld3(sbase + (size_t)i00 * C3), bb = ld3(sbase + (size_t)i01 * C3);
+        const f3 cc = ld3(sbase + (size_t)i10 * C3), dd = ld3(sbase + (size_t)i11 * C3);
+        const f3 go = ld3(dG + ((((size_t)s * NG + i) * d.B + b) * HW + p) * 3);
+        gx_ = gl * (go.x * (wy0 * (cc.x - a.x) + wy1 * (dd.x - bb.x)) + go.y * (wy0 * (cc.y - a.y) + wy1 * (dd.y - bb.y)) +
+                    go.z * (wy0 * (cc.z - a.z) + wy1 * (dd.z - bb.z)));
+        gy_ = gl * (go.x * (wx0 * (bb.x - a.x) + wx1 * (dd.x - cc.x)) + go.y * (wx0 * (bb.y - a.y) + wx1 * (dd.y - cc.y)) +
+                    go.z * (wx0 * (bb.z - a.z) + wx1 * (dd.z - cc.z)));
       }
+      const SplatW sw = splat_weights(g.x, g.y, c, true, g.z);
+      const int idx[4] = {i00, i01, i10, i11};
+      float dgk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 ha = *reinterpret_cast<const float4*>(hb + (size_t)idx[q] * 4);
+        const float4 hv = *reinterpret_cast<const float4*>(hb + hb_plane + (size_t)idx[q] * 4);
+        const float da = ((ha.x * tv.x + ha.y * tv.y) + ha.z * tv.z) - ha.w;
+        const float dv = ((hv.x * tv.x + hv.y * tv.y) + hv.z * tv.z) - hv.w;
+        dgk[q] = (gl * da + kv[i] * dv) * sw.g[q];
+      }
+      gx_ += -(dgk[0] + dgk[1]) * sw.dx0 + (dgk[2] + dgk[3]) * sw.dx1;
+      gy_ += -(dgk[0] + dgk[2]) * sw.dy0 + (dgk[1] + dgk[3]) * sw.dy1;
+      gz_ = -0.25f * sw.zin * ((dgk[0] + dgk[1]) + (dgk[2] + dgk[3]));
+      float dd_;
+      geom_bwd(ps[i], g, dep, true, t.x, t.y, t.z, gx_, gy_, gz_, dd_, dts[3 * i], dts[3 * i + 1], dts[3 * i + 2], dp[i]);
+      ddsum += dd_;
     }
-    __syncthreads();  // red is reused per source
-    block_sum_store<12>(dp, red,
-                        dPp + ((((size_t)s * d.N + i) * d.B + b) * gridDim.x + blockIdx.x) * 12);
+    d_depth[sb + p] = ddsum;
+#pragma unroll
+    for (int i = 0; i < N; ++i) st3(d_trans + (sb + p) * C3 + 3 * i, dts[3 * i], dts[3 * i + 1], dts[3 * i + 2]);
   }
 #pragma unroll
-  for (int it = 0; it < kLossPPT; ++it) {
-    const int p = (blockIdx.x * kLossPPT + it) * kBlock + threadIdx.x;
-    if (p < HW) d_depth[sb + p] = ddsum[it];
+  for (int i = 0; i < N; ++i) {
+    if (i) __syncthreads();  // red is reused per source
+    block_sum_store<12>(dp[i], red, dPp + ((((size_t)s * N + i) * d.B + b) * ntile + tile) * 12);
   }
 }
 
@@ -513,8 +530,8 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
                      trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift,
                      kReachAdd, kReachMin, kReachMax); }
   { StageTimer t(ST_WARP_FWD, stream);
-  hipLaunchKernelGGL(loss_splat_tile_kernel, dim3(w.stiles_x, w.stiles_y, w.n_img), dim3(kBlock), 0, stream, tgt, src,
-                     depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
+  hipLaunchKernelGGL(loss_splat_tile_kernel, dim3((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img)), dim3(kBlock), 0,
+                     stream, tgt, src, depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
                      flags); }
   int rc = sfm_last_error();
   if (rc) return rc;
@@ -552,9 +569,14 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
     return e != hipSuccess ? (int)e : sfm_last_error();
   }
   { StageTimer t(ST_WARP_BWD, stream);
-  hipLaunchKernelGGL(loss_warp_bwd_kernel, dim3(w.nblk_bwd, B, S), dim3(kBlock), 0, stream, tgt, src, depth, trans,
-                     params, ws + w.Hb, ws + w.dG, ws + w.coef, d, sfm_lin_step(W), sfm_lin_step(H), d_depth, d_trans,
-                     ws + w.dPp, ws + w.Ovf, flags); }
+  const dim3 grid((unsigned)((long)S * B * w.nblk_bwd));
+#define SFM_LAUNCH_BWD(NSRC)                                                                                          \
+  hipLaunchKernelGGL(loss_warp_bwd_kernel<NSRC>, grid, dim3(kBlock), 0, stream, tgt, src, depth, trans, params,      \
+                     ws + w.Hb, ws + w.dG, ws + w.coef, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, \
+                     d_depth, d_trans, ws + w.dPp, ws + w.Ovf, flags)
+  if (N == 2) SFM_LAUNCH_BWD(2); else if (N == 3) SFM_LAUNCH_BWD(3); else SFM_LAUNCH_BWD(4);
+#undef SFM_LAUNCH_BWD
+  }
   int rc = sfm_last_error();
   if (rc) return rc;
   // pose [B,N,6]: element (b,i,k) at b*6N + i*6 + k; partial sets = scales

@@ -51,7 +51,7 @@ static inline StencilPlan stencil_plan(const LossDims& d, int rows_override) {
 //   wavep [n_waves][4]  per-wave partial sums of the stencil kernel
 //   dPp [S,N,B,nblk,12] dL/dP block partials of the backward warp
 constexpr int STW = 64, STH = 16;  // splat: destination tile of one workgroup
-constexpr int kLossPPT = 4;        // pixels per thread in the backward warp kernel
+constexpr int kLossPPT = STW * STH / kBlock;  // pixels per thread in the backward warp kernel (one tile per workgroup)
 
 struct LossWs {
   size_t G, Acc, Ovf, Hb, dG, wavep, dPp, coef, shift, flags, total;
@@ -64,9 +64,9 @@ static inline LossWs loss_ws(const LossDims& d, const StencilPlan& sp) {
   LossWs w;
   const size_t npx = (size_t)d.B * d.H * d.W;
   const int ng = d.N < 2 ? d.N : 2;
-  w.nblk_bwd = (d.H * d.W + kBlock * kLossPPT - 1) / (kBlock * kLossPPT);
   w.stiles_x = (d.W + STW - 1) / STW;
   w.stiles_y = (d.H + STH - 1) / STH;
+  w.nblk_bwd = w.stiles_x * w.stiles_y;  // the backward warp uses the same tiling
   w.n_img = d.S * d.N * d.B;
   size_t o = 0;
   w.Acc = o; o += (size_t)d.S * d.N * npx * 4;

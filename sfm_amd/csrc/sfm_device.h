@@ -162,6 +162,16 @@ __device__ __forceinline__ SplatW splat_weights(float x, float y, const Corners&
   return s;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks L and L + 8 share an XCD and its L2;
+// MI355X_MICROARCH.md "Workgroup dispatch").  xcd_contiguous(L, T) renumbers a 1-D grid of T blocks so
+// that each XCD works on one contiguous range of the renumbered ids: neighbouring tiles then share an L2
+// and their overlapping halos are fetched from HBM once.  A bijection on [0, T); speed only, never
+// correctness.
+__device__ __forceinline__ int xcd_contiguous(int L, int T) {
+  const int per = T >> 3, rem = T & 7, x = L & 7;
+  return x * per + min(x, rem) + (L >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
