@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
 }
 
 // grid: tiles_x * tiles_y * S*N*B blocks (1-D), 256 threads.
-__global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __restrict__ tgt,
+__global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const float* __restrict__ tgt,
                                                                  const float* __restrict__ src,
                                                                  const float* __restrict__ depth,
                                                                  const float* __restrict__ trans,
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
   const bool home_covered = (RW > 0 && RH > 0 && sxl <= x0 && sxh >= x1 && syl <= y0 && syh >= y1);
   const int n_all = n_scan + (home_covered ? 0 : TP);
   const float inv_rw = RW > 0 ? 1.0f / (float)RW : 0.0f;
-  for (int k = threadIdx.x; k < 4 * TP; k += kBlock) acc[k] = 0.0;
+  for (int k = threadIdx.x; k < 4 * TP; k += kSplatThreads) acc[k] = 0.0;
   // scan windows of the tiles this tile's pixels can land in (the neighbourhood of where its centre
   // lands), cached in LDS for the overflow test; anything further away is looked up in memory
   const int ctx0 = min(max(x0 + STW / 2 + mine.x, 0), d.W - 1) / STW - kCacheTX;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
   float* __restrict__ ovf = Ovf + (size_t)img * HW * 4;
   bool flagged = false;
 
-  for (int k = threadIdx.x; k < n_all; k += kBlock) {
+  for (int k = threadIdx.x; k < n_all; k += kSplatThreads) {
     int u, v;
     bool scan;
     if (k < n_scan) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void loss_splat_tile_kernel(const float* __
   if (flagged) flags[img] = 1;
   __syncthreads();
   float* __restrict__ accg = Acc + (size_t)img * HW * 4;
-  for (int k = threadIdx.x; k < TP; k += kBlock) {
+  for (int k = threadIdx.x; k < TP; k += kSplatThreads) {
     const int u = x0 + (k & (STW - 1)), v = y0 + (k / STW);
     if (u < x1 && v < y1)
       *reinterpret_cast<float4*>(accg + ((size_t)v * d.W + u) * 4) =
@@ -324,7 +324,7 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
 }
 
 // ------------------------------------------------------------------ fused warp backward
-// One workgroup = one STW x STH pixel tile of one (scale, batch item): 2-D tiles keep the footprint of
+// One workgroup = one BTW x BTH pixel tile of one (scale, batch item): 2-D tiles keep the footprint of
 // the corner gathers (Hb, source taps) close to the tile itself, and the XCD-contiguous block order
 // (sfm_device.h) puts neighbouring tiles behind the same L2, so their overlapping halos are fetched
 // from HBM once.  A thread owns kLossPPT pixels; per pixel it walks the N sources (compile-time N: the
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
   const int ntile = tiles_x * tiles_y;
   const int blk = xcd_contiguous(blockIdx.x, gridDim.x);  // (s*B + b)*ntile + tile
   const int tile = blk % ntile, sbi = blk / ntile, b = sbi % d.B, s = sbi / d.B;
-  const int x0 = (tile % tiles_x) * STW, y0 = (tile / tiles_x) * STH;
+  const int x0 = (tile % tiles_x) * BTW, y0 = (tile / tiles_x) * BTH;
   const int HW = d.H * d.W;
   const size_t img = (size_t)b * HW;
   const size_t sb = ((size_t)s * d.B + b) * HW;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
 #pragma unroll 1
   for (int it = 0; it < kLossPPT; ++it) {
     const int k = it * kBlock + threadIdx.x;
-    const int u = x0 + (k & (STW - 1)), v = y0 + k / STW;
+    const int u = x0 + (k & (BTW - 1)), v = y0 + k / BTW;
     if (u >= d.W || v >= d.H) continue;
     const int p = v * d.W + u;
     const float dep = depth[sb + p];
@@ -530,7 +530,7 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
                      trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift,
                      kReachAdd, kReachMin, kReachMax); }
   { StageTimer t(ST_WARP_FWD, stream);
-  hipLaunchKernelGGL(loss_splat_tile_kernel, dim3((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(loss_splat_tile_kernel, dim3((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img)), dim3(kSplatThreads), 0,
                      stream, tgt, src, depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
                      flags); }
   int rc = sfm_last_error();
@@ -572,7 +572,7 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   const dim3 grid((unsigned)((long)S * B * w.nblk_bwd));
 #define SFM_LAUNCH_BWD(NSRC)                                                                                          \
   hipLaunchKernelGGL(loss_warp_bwd_kernel<NSRC>, grid, dim3(kBlock), 0, stream, tgt, src, depth, trans, params,      \
-                     ws + w.Hb, ws + w.dG, ws + w.coef, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, \
+                     ws + w.Hb, ws + w.dG, ws + w.coef, d, sfm_lin_step(W), sfm_lin_step(H), w.btiles_x, w.btiles_y, \
                      d_depth, d_trans, ws + w.dPp, ws + w.Ovf, flags)
   if (N == 2) SFM_LAUNCH_BWD(2); else if (N == 3) SFM_LAUNCH_BWD(3); else SFM_LAUNCH_BWD(4);
 #undef SFM_LAUNCH_BWD

@@ -50,12 +50,17 @@ static inline StencilPlan stencil_plan(const LossDims& d, int rows_override) {
 //   dG  [S,2,B,H,W,3]   backward: dL/dG_i (gloss = 1)
 //   wavep [n_waves][4]  per-wave partial sums of the stencil kernel
 //   dPp [S,N,B,nblk,12] dL/dP block partials of the backward warp
-constexpr int STW = 64, STH = 16;  // splat: destination tile of one workgroup
-constexpr int kLossPPT = STW * STH / kBlock;  // pixels per thread in the backward warp kernel (one tile per workgroup)
+#ifndef SFM_STH
+#define SFM_STH 32
+#endif
+constexpr int STW = 64, STH = SFM_STH;  // splat: destination tile of one workgroup (LDS: 4 fp64 planes)
+constexpr int kSplatThreads = STW * STH / 4;  // 4 home pixels per thread
+constexpr int BTW = 64, BTH = 16;  // backward warp: pixel tile of one workgroup
+constexpr int kLossPPT = BTW * BTH / kBlock;  // pixels per thread in the backward warp kernel
 
 struct LossWs {
   size_t G, Acc, Ovf, Hb, dG, wavep, dPp, coef, shift, flags, total;
-  int nblk_bwd, stiles_x, stiles_y, n_img;
+  int nblk_bwd, btiles_x, btiles_y, stiles_x, stiles_y, n_img;
 };
 
 static inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
@@ -66,7 +71,9 @@ static inline LossWs loss_ws(const LossDims& d, const StencilPlan& sp) {
   const int ng = d.N < 2 ? d.N : 2;
   w.stiles_x = (d.W + STW - 1) / STW;
   w.stiles_y = (d.H + STH - 1) / STH;
-  w.nblk_bwd = w.stiles_x * w.stiles_y;  // the backward warp uses the same tiling
+  w.btiles_x = (d.W + BTW - 1) / BTW;
+  w.btiles_y = (d.H + BTH - 1) / BTH;
+  w.nblk_bwd = w.btiles_x * w.btiles_y;
   w.n_img = d.S * d.N * d.B;
   size_t o = 0;
   w.Acc = o; o += (size_t)d.S * d.N * npx * 4;

@@ -380,17 +380,17 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
   if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sE, 0.f, 0.f, 0.f);
 }
 
-// One wave per work item, 4 independent waves per block, blocks in XCD-contiguous order (the halo
-// rows / columns of neighbouring strips and chunks are then served by the same L2).  Two kernels because the register
+// One wave per work item, 4 independent waves per block (plain round-robin block order: the
+// XCD-contiguous order measured 25 % MORE fetched bytes here - profiles/r01_traffic.md).  Two kernels because the register
 // budgets differ (the gather side carries two SSIMs per channel).
 template <bool GRAD>
 __global__ __launch_bounds__(kBlock) void loss_stencil_gather_kernel(StencilArgs a) {
-  const long w = (long)xcd_contiguous(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (w < a.p.n_gather) gather_item<GRAD>(a, w, a.wavep + (a.p.n_splat + w) * kWaveTerms);
 }
 template <bool GRAD>
 __global__ __launch_bounds__(kBlock) void loss_stencil_splat_kernel(StencilArgs a) {
-  const long w = (long)xcd_contiguous(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (w < a.p.n_splat) splat_item<GRAD>(a, w, a.wavep + w * kWaveTerms);
 }
 
