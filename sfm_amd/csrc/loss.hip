@@ -297,12 +297,17 @@ __global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ finalize
-// partials (global sums) -> loss and the coefficients the backward warp combines the two parts
-// of Hb with:  coef[0] = gloss ;  coef[1 + s*N + i] = gloss * kV(s, i),
-// kV = (1 - alpha) (M / n) (-1/2) [clip passes] / n   (d/dSp of (1-alpha) mean(m) clip((1 - V/n)/2, 0, 1)).
-__global__ void loss_finalize_kernel(const double* __restrict__ partials, int S, int N, double n_elem, float gloss,
-                                     float* __restrict__ coef, float* __restrict__ loss_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// partials (global sums) -> loss and the coefficient the backward warp scales the SSIM part of Hb with:
+// kV(s, i) = (1 - alpha) (M / n) (-1/2) [clip passes] / n   (d/dSp of (1-alpha) mean(m) clip((1 - V/n)/2, 0, 1)).
+__device__ __forceinline__ float loss_kv(const double* __restrict__ partials, int N, int s, int i, double n_elem) {
+  const int nterm = 3 * N + 1;
+  const double M = partials[s * nterm + 3 * i + 1], V = partials[s * nterm + 3 * i + 2];
+  const float h = (1.0f - (float)(V / n_elem)) / 2.0f;
+  const double pass = (h >= 0.0f && h <= 1.0f) ? 1.0 : 0.0;
+  return (float)((1.0 - (double)kAlpha) * (M / n_elem) * (-0.5) * pass / n_elem);
+}
+
+__device__ __forceinline__ float loss_value(const double* __restrict__ partials, int S, int N, double n_elem) {
   const int nterm = 3 * N + 1;
   const double a = (double)kAlpha;
   double loss = 0.0;
@@ -310,17 +315,19 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
     for (int i = 0; i < N; ++i) {
       const double A = partials[s * nterm + 3 * i], M = partials[s * nterm + 3 * i + 1],
                    V = partials[s * nterm + 3 * i + 2];
-      const float vmean = (float)(V / n_elem);
-      const float h = (1.0f - vmean) / 2.0f;
+      const float h = (1.0f - (float)(V / n_elem)) / 2.0f;
       const float sc = fminf(fmaxf(h, 0.0f), 1.0f);
-      const double pass = (h >= 0.0f && h <= 1.0f) ? 1.0 : 0.0;
       loss += a * (A / n_elem) + (1.0 - a) * (double)sc * (M / n_elem);
-      coef[1 + s * N + i] = (float)((double)gloss * (1.0 - a) * (M / n_elem) * (-0.5) * pass / n_elem);
     }
     loss += 2.0 * partials[s * nterm + 3 * N] / n_elem;
   }
-  coef[0] = gloss;
-  *loss_out = (float)loss;
+  return (float)loss;
+}
+
+// forward-only steps: just the loss (with gradients, the backward warp kernel does this itself)
+__global__ void loss_finalize_kernel(const double* __restrict__ partials, int S, int N, double n_elem,
+                                     float* __restrict__ loss_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *loss_out = loss_value(partials, S, N, n_elem);
 }
 
 // ------------------------------------------------------------------ fused warp backward
@@ -339,8 +346,9 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
                                                                const float* __restrict__ params,
                                                                const float* __restrict__ Hb,
                                                                const float* __restrict__ dG,
-                                                               const float* __restrict__ coef, LossDims d, float step_x,
-                                                               float step_y, int tiles_x, int tiles_y,
+                                                               const double* __restrict__ partials, double n_elem,
+                                                               float gl, float* __restrict__ loss_out, LossDims d,
+                                                               float step_x, float step_y, int tiles_x, int tiles_y,
                                                                float* __restrict__ d_depth,
                                                                float* __restrict__ d_trans,
                                                                float* __restrict__ dPp, float* __restrict__ Ovf,
@@ -355,7 +363,8 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
   const size_t img = (size_t)b * HW;
   const size_t sb = ((size_t)s * d.B + b) * HW;
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
-  const float gl = coef[0];  // dL/d loss
+  // gl = dL/d loss.  The loss itself is one thread's job
+  if (blockIdx.x == 0 && threadIdx.x == 0) *loss_out = loss_value(partials, d.S, N, n_elem);
   const size_t hb_plane = (size_t)d.S * N * d.B * HW * 4;
   Pose ps[N];
   float kv[N], dp[N][12];
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     ps[i] = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-    kv[i] = coef[1 + s * N + i];  // gloss * kV(s, i)
+    kv[i] = gl * loss_kv(partials, N, s, i, n_elem);  // wave-uniform (scalar loads)
     clr[i] = flags[(s * N + i) * d.B + b] != 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) dp[i][k] = 0.0f;
@@ -482,10 +491,6 @@ static inline LossLayout loss_layout(const LossDims& d) {
 
 using namespace sfm;
 
-// from pose.hip
-extern "C" int sfm_pose_grad(const float* pose, long pose_sb, long pose_si, const float* K, const float* partials,
-                             int n_sets, int nblk, int B, int n_src, int inverse_pose, float gscale, float* d_pose,
-                             long dpose_sb, long dpose_si, void* stream);
 
 extern "C" long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N) {
   LossDims d{B, H, W, S, N};
@@ -560,10 +565,9 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_layout(d).w;
   int* flags = reinterpret_cast<int*>(ws + w.flags);
-  { StageTimer t(ST_FINALIZE, stream);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, gloss,
-                     ws + w.coef, loss_out); }
-  if (!need_grad) {  // forward-only step: restore the Ovf / flags invariant here
+  if (!need_grad) {  // forward-only step: the loss, and restore the Ovf / flags invariant here
+    { StageTimer t(ST_FINALIZE, stream);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, loss_out); }
     hipLaunchKernelGGL(loss_ovf_clear_kernel, dim3(64, w.n_img), dim3(kBlock), 0, stream, ws + w.Ovf, flags, H * W);
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_img * sizeof(int), stream);
     return e != hipSuccess ? (int)e : sfm_last_error();
@@ -572,7 +576,8 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   const dim3 grid((unsigned)((long)S * B * w.nblk_bwd));
 #define SFM_LAUNCH_BWD(NSRC)                                                                                          \
   hipLaunchKernelGGL(loss_warp_bwd_kernel<NSRC>, grid, dim3(kBlock), 0, stream, tgt, src, depth, trans, params,      \
-                     ws + w.Hb, ws + w.dG, ws + w.coef, d, sfm_lin_step(W), sfm_lin_step(H), w.btiles_x, w.btiles_y, \
+                     ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, gloss, loss_out, d, sfm_lin_step(W),       \
+                     sfm_lin_step(H), w.btiles_x, w.btiles_y,                                                        \
                      d_depth, d_trans, ws + w.dPp, ws + w.Ovf, flags)
   if (N == 2) SFM_LAUNCH_BWD(2); else if (N == 3) SFM_LAUNCH_BWD(3); else SFM_LAUNCH_BWD(4);
 #undef SFM_LAUNCH_BWD
@@ -581,10 +586,9 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   if (rc) return rc;
   // pose [B,N,6]: element (b,i,k) at b*6N + i*6 + k; partial sets = scales
   StageTimer t(ST_POSE_GRAD, stream);
-  rc = sfm_pose_grad(pose, 6L * N, 6L, K, ws + w.dPp, S, w.nblk_bwd, B, N, 0, 1.0f, d_pose, 6L * N, 6L, stream_);
-  if (rc) return rc;
-  hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_img * sizeof(int), stream);  // Ovf was re-zeroed by warp_bwd
-  return e == hipSuccess ? SFM_OK : (int)e;
+  // the last kernel of the step also lowers the overflow flags (Ovf itself was re-zeroed by warp_bwd)
+  return sfm_launch_pose_grad(pose, 6L * N, 6L, K, ws + w.dPp, S, w.nblk_bwd, B, N, 0, 1.0f, d_pose, 6L * N, 6L, flags,
+                              w.n_img, stream);
 }
 
 // ---- measurement aid (bench.py): per-launch HIP-event timing of the two calls above ----

@@ -118,8 +118,11 @@ __global__ __launch_bounds__(kBlock) void pose_grad_kernel(const float* __restri
                                                            const float* __restrict__ K,
                                                            const float* __restrict__ partials, int n_sets, int nblk,
                                                            int B, int n_src, int inverse_pose, float gscale,
-                                                           float* __restrict__ d_pose, long dpose_sb, long dpose_si) {
+                                                           float* __restrict__ d_pose, long dpose_sb, long dpose_si,
+                                                           int* __restrict__ zero, int n_zero) {
   __shared__ double red[4][12];
+  if (zero)  // optional: words the caller wants cleared by the last kernel of its step
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < n_zero; k += gridDim.x * kBlock) zero[k] = 0;
   const int j = blockIdx.x;
   const int i = j / B, b = j - i * B;
   const float* pv = pose + b * pose_sb + i * pose_si;
@@ -243,12 +246,19 @@ extern "C" int sfm_pose_setup(const float* pose, long pose_sb, long pose_si, con
   return sfm_last_error();
 }
 
+int sfm_launch_pose_grad(const float* pose, long pose_sb, long pose_si, const float* K, const float* partials, int n_sets,
+                         int nblk, int B, int n_src, int inverse_pose, float gscale, float* d_pose, long dpose_sb,
+                         long dpose_si, int* zero, int n_zero, hipStream_t stream) {
+  if (!pose || !K || !partials || !d_pose || B <= 0 || n_src <= 0 || nblk <= 0 || n_sets <= 0) return SFM_ERR_ARG;
+  int items = B * n_src;
+  hipLaunchKernelGGL(sfm::pose_grad_kernel, dim3(items), dim3(sfm::kBlock), 0, stream, pose, pose_sb, pose_si, K, partials,
+                     n_sets, nblk, B, n_src, inverse_pose, gscale, d_pose, dpose_sb, dpose_si, zero, n_zero);
+  return sfm_last_error();
+}
+
 extern "C" int sfm_pose_grad(const float* pose, long pose_sb, long pose_si, const float* K, const float* partials,
                              int n_sets, int nblk, int B, int n_src, int inverse_pose, float gscale, float* d_pose,
                              long dpose_sb, long dpose_si, void* stream) {
-  if (!pose || !K || !partials || !d_pose || B <= 0 || n_src <= 0 || nblk <= 0 || n_sets <= 0) return SFM_ERR_ARG;
-  int items = B * n_src;
-  hipLaunchKernelGGL(pose_grad_kernel, dim3(items), dim3(kBlock), 0, (hipStream_t)stream, pose, pose_sb, pose_si, K,
-                     partials, n_sets, nblk, B, n_src, inverse_pose, gscale, d_pose, dpose_sb, dpose_si);
-  return sfm_last_error();
+  return sfm_launch_pose_grad(pose, pose_sb, pose_si, K, partials, n_sets, nblk, B, n_src, inverse_pose, gscale, d_pose,
+                              dpose_sb, dpose_si, nullptr, 0, (hipStream_t)stream);
 }

@@ -17,3 +17,8 @@ static inline float sfm_lin_step(int n) { return n > 1 ? 2.0f / (float)(n - 1) :
 
 // every per-image element count must stay below 2^31 (kernels index an image with int)
 static inline bool sfm_fits(long h, long w, long per_pixel) { return h * w * per_pixel < 2147483647L; }
+
+// pose.hip: sfm_pose_grad plus an optional list of words to clear (used by the fused loss)
+int sfm_launch_pose_grad(const float* pose, long pose_sb, long pose_si, const float* K, const float* partials, int n_sets,
+                         int nblk, int B, int n_src, int inverse_pose, float gscale, float* d_pose, long dpose_sb,
+                         long dpose_si, int* zero, int n_zero, hipStream_t stream);
