@@ -11,7 +11,7 @@
 //
 // Work decomposition: one WAVE owns a strip of 60 image columns (64 lanes, 2 halo lanes on each
 // side) and marches down `rows` image rows.  Horizontal neighbours come from the adjacent lanes
-// by DPP wave shifts (v_*_dpp wave_shr:1 / wave_shl:1, full VALU rate), vertical neighbours from
+// by DPP wave shifts (v_*_dpp wave_shr:1 / wave_shl:1: no LDS, half the plain VALU rate), vertical neighbours from
 // a 3-row sliding window held in registers; the 3x3 Gaussian window of tf_ssim is separable
 // (w_ij = g_i g_j), so every windowed moment is one horizontal and one vertical 3-tap pass.
 // The chained second stencil of the backward (dSSIM/dx = conv(a) + 2 x conv(b) + y conv(c), the

@@ -1,6 +1,6 @@
 """Per-layer timing of the 11 dilated 3x3 convolutions of disp_aspp_u_dense at config 5 (B=8, 416x128)."""
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sfm_amd
 from sfm_amd import _lib
 from sfm_amd._lib import call, ptr, stream_of

@@ -1,7 +1,7 @@
 """Fused loss step at the per-GPU slices of BASELINE.json configs[1..3] (1 GPU): ms/step, Gpix/s, fraction of
 the 8 TB/s roofline at SURVEY 8(d)'s 260 B per (pixel, scale, source)."""
 import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sfm_amd import synth
 from sfm_amd.loss import LossEngine
 dev = torch.device("cuda:0")

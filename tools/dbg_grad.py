@@ -1,6 +1,6 @@
 """Debug aid: fused HIP gradients vs the oracle in fp32 and fp64, with near-tie exclusion."""
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sfm_amd
 from sfm_amd import synth
 from oracle import ref_graph as R

@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc.sh <tag> "<counters>"  -> per-kernel mean of each counter (one pass = one run)
+# usage (on the GPU box): tools/pmc.sh <tag> "<counters>" [script [args...]]  -> per-kernel mean of each counter (one pass = one run)
 set -e
-tag=$1; ctr=$2
+tag=$1; ctr=$2; script=${3:-bench.py}; shift 3 2>/dev/null || true
+args=${@:---steps 10 --warmup 2 --no-cpu-baseline --no-aspp}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 rm -rf $out
-timeout -s KILL 120 rocprofv3 --pmc $ctr --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc $ctr --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/$script $args > $out.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
