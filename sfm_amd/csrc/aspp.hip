@@ -245,9 +245,139 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
   store_acc<TM, TN>(acc, o, Cout, ci0 + wm0, Cin, co0 + wn0);
 }
 
-// out[e] = sum_z part[z][e], z ascending (fixed order)
+// ------------------------------------------------------------------ backward weight, all 9 taps at once
+// For layers whose whole Cin x Cout block is small (the last decoder levels: 64 -> 32) one tap per
+// workgroup leaves a 64x32 tile with 10 flop/byte - L2-bandwidth bound.  Here a workgroup owns a
+// 64 (ci) x 32 (co) block of ALL NINE taps: a K-step is a segment of 32 consecutive pixels of one
+// image row; the input patch (3 rows x (32 + 2 rate) pixels x 64 channels) and the 32 x 32 gout
+// tile are staged once and every tap reads the patch at its own offset.  3 waves, wave w = tap
+// row dy = (w - 1) rate, 3 taps x 2 MFMA tiles each.  36 flop/byte at rate 3.
+// grid ((Cin / 64) * (Cout / 32), splits); a split covers row segments [z * sps, (z + 1) * sps).
+constexpr int kSegMaxRate = 16;
+__global__ __launch_bounds__(192, 2) void aspp_wgrad9_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                          float* __restrict__ gw, int B, int H, int W, int Cin, int Cout,
+                                                          int rate, long sps) {
+  constexpr int BM = 64, BN = 32, LDA = BM + 4, LDB = BN + 4, NT = 192;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PW = BK + 2 * rate;              // patch width in pixels
+  float* As = lds;                           // [3][PW][LDA]
+  float* Bs = lds + 3 * PW * LDA;            // [BK][LDB]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int ntn = Cout / BN;
+  const int ci0 = (blockIdx.x / ntn) * BM, co0 = (blockIdx.x % ntn) * BN;
+  const int nseg = (W + BK - 1) / BK;
+  const long nsteps = (long)B * H * nseg;
+  const long s0 = (long)blockIdx.y * sps, s1 = min(nsteps, s0 + sps);
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[j][i][reg] = 0.f;
+
+  // staging: every thread owns up to kAIt float4 of the patch and kBIt of the gout tile; the next step's
+  // global loads are issued into registers before the MFMAs of the current one
+  constexpr int kAIt = 3 * (BK + 2 * kSegMaxRate) * (BM / 4) / NT, kBIt = (BK * (BN / 4) + NT - 1) / NT;
+  const int na4 = 3 * PW * (BM / 4);
+  float4 ra[kAIt], rb[kBIt];
+  auto load_step = [&](long row, int seg) {   // row = b * H + y
+    const int y = (int)(row % H);
+    const long rbase = row - y;
+    const int xs = seg * BK;
+#pragma unroll
+    for (int it = 0; it < kAIt; ++it) {
+      const int idx = it * NT + tid;
+      const int c4 = idx % (BM / 4), pp = idx / (BM / 4), px = pp % PW, pr = pp / PW;
+      const int yy = y + (pr - 1) * rate, xx = xs - rate + px;
+      ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < na4 && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        ra[it] = *reinterpret_cast<const float4*>(in + ((rbase + yy) * W + xx) * Cin + ci0 + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < kBIt; ++it) {
+      const int idx = it * NT + tid, n4 = idx % (BN / 4), k = idx / (BN / 4);
+      rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < BK && xs + k < W) rb[it] = *reinterpret_cast<const float4*>(gout + (row * W + xs + k) * Cout + co0 + n4 * 4);
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int it = 0; it < kAIt; ++it) {
+      const int idx = it * NT + tid;
+      if (idx < na4) *reinterpret_cast<float4*>(&As[(idx / (BM / 4)) * LDA + (idx % (BM / 4)) * 4]) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < kBIt; ++it) {
+      const int idx = it * NT + tid, n4 = idx % (BN / 4), k = idx / (BN / 4);
+      if (k < BK) *reinterpret_cast<float4*>(&Bs[k * LDB + n4 * 4]) = rb[it];
+    }
+  };
+
+  long row = s0 / nseg;              // (image row, segment) of the step being loaded, advanced incrementally
+  int seg = (int)(s0 - row * nseg);
+  if (s0 < s1) load_step(row, seg);
+  for (long s = s0; s < s1; ++s) {
+    store_step();
+    __syncthreads();
+    if (++seg == nseg) { seg = 0; ++row; }
+    if (s + 1 < s1) load_step(row, seg);
+    const float* Aw = As + wave * PW * LDA;
+#pragma unroll 4
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float b = Bs[(kk + h) * LDB + r];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float* ap = Aw + (kk + h + j * rate) * LDA + r;   // input pixel k + (j - 1) rate = patch pixel k + j rate
+        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[0], b, acc[j][0], 0, 0, 0);
+        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32], b, acc[j][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* o = gw + (long)blockIdx.y * 9 * Cin * Cout;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float* ot = o + (long)(wave * 3 + j) * Cin * Cout;
+    const int c = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rr = ci0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        ot[(long)rr * Cout + co0 + c] = acc[j][i][reg];
+      }
+  }
+}
+
+// out[e] = sum_z part[z][e] in a fixed order: a workgroup owns 16 float4 outputs, 16 thread groups
+// each add every 16th slab (independent loads in flight), LDS combines the groups in group order.
 __global__ __launch_bounds__(kBlock) void aspp_reduce_kernel(const float* __restrict__ part, long n4, int splits,
                                                              float* __restrict__ out) {
+  __shared__ float4 red[16][16];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long e = (long)blockIdx.x * 16 + o;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < n4)
+    for (int z = g; z < splits; z += 16) {
+      const float4 v = reinterpret_cast<const float4*>(part)[(long)z * n4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[g][o] = s;
+  __syncthreads();
+  if (g == 0 && e < n4) {
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = red[k][o];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[e] = s;
+  }
+}
+
+// the same for a handful of slabs: one thread per float4, slabs in order
+__global__ __launch_bounds__(kBlock) void aspp_reduce_few_kernel(const float* __restrict__ part, long n4, int splits,
+                                                                 float* __restrict__ out) {
   const long e = (long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= n4) return;
   float4 s = reinterpret_cast<const float4*>(part)[e];
@@ -256,6 +386,14 @@ __global__ __launch_bounds__(kBlock) void aspp_reduce_kernel(const float* __rest
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   reinterpret_cast<float4*>(out)[e] = s;
+}
+
+static void launch_reduce(const float* part, long n4, int splits, float* out, hipStream_t stream) {
+  if (splits <= 16)
+    hipLaunchKernelGGL(aspp_reduce_few_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, part, n4,
+                       splits, out);
+  else
+    hipLaunchKernelGGL(aspp_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(kBlock), 0, stream, part, n4, splits, out);
 }
 
 // wt[t][co][ci] = w[8 - t][ci][co]: the backward-data problem as a forward convolution
@@ -299,14 +437,24 @@ static ConvPlan conv_plan(long M, int Cin, int Cout) {
 }
 
 struct WgradPlan {
-  int cfg;  // 0: 128x128, 1: 128x64, 2: 64x32, 3: 32x32
+  int cfg;  // 0: 128x128, 1: 128x64, 2: 64x32, 3: 32x32, 4: 64x32 x 9 taps on row segments (pps = segments per split)
   int bm, bn;
   int splits;
   long pps;  // pixels per split, multiple of BK
 };
 
-static WgradPlan wgrad_plan(long M, int Cin, int Cout) {
+static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, int rate) {
+  const long M = (long)B * H * W;
   WgradPlan p;
+  if (Cin % 64 == 0 && (Cin % 128 != 0 || Cout % 64 != 0) && rate <= kSegMaxRate && W >= BK) {
+    p.cfg = 4; p.bm = 64; p.bn = 32;
+    const long nsteps = (long)B * H * ((W + BK - 1) / BK), base = (long)(Cin / 64) * (Cout / 32);
+    long splits = (768 + base - 1) / base;               // ~3 workgroups of 3 waves per CU
+    if (splits > nsteps / 8) splits = nsteps / 8 > 0 ? nsteps / 8 : 1;
+    p.pps = (nsteps + splits - 1) / splits;
+    p.splits = (int)((nsteps + p.pps - 1) / p.pps);
+    return p;
+  }
   if (Cin % 128 == 0 && Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
   else if (Cin % 128 == 0 && Cout % 64 == 0) { p.cfg = 1; p.bm = 128; p.bn = 64; }
   else if (Cin % 64 == 0) { p.cfg = 2; p.bm = 64; p.bn = 32; }
@@ -345,8 +493,7 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
                        p.tps, stride);
   if (p.splits > 1) {
     const long n4 = stride / 4;
-    hipLaunchKernelGGL(aspp_reduce_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, slabs, n4,
-                       p.splits, out);
+    launch_reduce(slabs, n4, p.splits, out, stream);
   }
   return sfm_last_error();
 }
@@ -364,10 +511,10 @@ extern "C" long long sfm_aspp_conv3x3_workspace_floats(int B, int H, int W, int 
   if (!conv_dims_ok(B, H, W, Cin, Cout, 1)) return SFM_ERR_ARG;
   const long M = (long)B * H * W;
   const ConvPlan f = conv_plan(M, Cin, Cout), d = conv_plan(M, Cout, Cin);
-  const WgradPlan g = wgrad_plan(M, Cin, Cout);
+  const WgradPlan g = wgrad_plan(B, H, W, Cin, Cout, 1), g2 = wgrad_plan(B, H, W, Cin, Cout, kSegMaxRate + 1);
   const long fwd = f.splits > 1 ? (long)f.splits * M * Cout : 0;
   const long bwd = (d.splits > 1 ? (long)d.splits * M * Cin : 0) + 9L * Cin * Cout;
-  const long wg = g.splits > 1 ? (long)g.splits * 9 * Cin * Cout : 0;
+  const long wg = (long)(g.splits > g2.splits ? g.splits : g2.splits) * 9 * Cin * Cout;  // either weight-gradient kernel
   long n = fwd > bwd ? fwd : bwd;
   if (wg > n) n = wg;
   return n + 4;
@@ -397,11 +544,14 @@ extern "C" int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, i
                                            int rate, float* gw, float* ws, void* stream_) {
   if (!in || !gout || !gw || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  const long M = (long)B * H * W;
-  const WgradPlan p = wgrad_plan(M, Cin, Cout);
+  const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout, rate);
   float* dst = p.splits > 1 ? ws : gw;
   const dim3 grid((Cin / p.bm) * (Cout / p.bn), 9, p.splits);
-  if (p.cfg == 0)
+  if (p.cfg == 4) {
+    const size_t lds = (size_t)(3 * (BK + 2 * rate) * 68 + BK * 36) * sizeof(float);
+    hipLaunchKernelGGL(aspp_wgrad9_kernel, dim3((Cin / 64) * (Cout / 32), p.splits), dim3(192), lds, stream, in, gout, dst, B, H,
+                       W, Cin, Cout, rate, p.pps);
+  } else if (p.cfg == 0)
     hipLaunchKernelGGL((aspp_wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
                        rate, p.pps);
   else if (p.cfg == 1)
@@ -415,8 +565,7 @@ extern "C" int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, i
                        rate, p.pps);
   if (p.splits > 1) {
     const long n4 = 9L * Cin * Cout / 4;
-    hipLaunchKernelGGL(aspp_reduce_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws, n4,
-                       p.splits, gw);
+    launch_reduce(ws, n4, p.splits, gw, stream);
   }
   return sfm_last_error();
 }

@@ -18,7 +18,9 @@ CASES = [  # (B, H, W, Cin, Cout, rate): every tile configuration, ragged M, rat
     (1, 8, 26, 128, 64, 3),     # 128 -> 64
     (2, 8, 26, 256, 128, 4),    # 128-wide tiles, tap-split forward
     (1, 6, 6, 96, 160, 12),     # odd multiples of 32, rate larger than the image
-    (1, 16, 52, 64, 64, 6),
+    (1, 16, 52, 64, 64, 6),     # 9-tap row-segment weight gradient, ragged last segment
+    (2, 12, 40, 128, 32, 3),    # the same with two input-channel blocks
+    (1, 9, 70, 64, 32, 16),     # its largest rate
 ]
 
 
@@ -71,11 +73,18 @@ def test_bitwise_reproducible(dev):
 @pytest.mark.parametrize("h,w_,Cin,Cout,rate", [(8, 26, 1024, 512, 2), (128, 416, 64, 32, 12)],
                          ids=["concat 8x26 1024->512 r2", "concat4 128x416 64->32 r12"])
 def test_full_size_layers_of_config5(dev, h, w_, Cin, Cout, rate):
-    """The smallest-M and the largest-M layer of BASELINE.json configs[4] (B=8), forward against the oracle."""
+    """The smallest-M and the largest-M layer of BASELINE.json configs[4] (B=8): forward and weight gradient
+    (K = B*h*w up to 425 984 per tap) against the oracle."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(8, h, w_, Cin, generator=g)
     w = torch.randn(3, 3, Cin, Cout, generator=g) / (3.0 * Cin ** 0.5)
     torch.set_num_threads(16)
-    yo = R.dilated_conv3x3(x, w, rate)
-    yg = sfm_amd.dilated_conv3x3(x.to(dev), w.to(dev), rate)
+    go = torch.randn(8, h, w_, Cout, generator=g)
+    wo = w.clone().requires_grad_(True)
+    yo = R.dilated_conv3x3(x, wo, rate)
+    yo.backward(go)
+    wg = w.to(dev).requires_grad_(True)
+    yg = sfm_amd.dilated_conv3x3(x.to(dev), wg, rate)
+    yg.backward(go.to(dev))
     assert rel_err(yg, yo) <= TOL
+    assert rel_err(wg.grad, wo.grad) <= TOL
