@@ -68,7 +68,9 @@ __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], float* __
 // grid (ceil(M / BM), Cout / BN, splits); a split covers taps [z * tps, (z + 1) * tps) and writes
 // its own slab out + z * split_stride.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void aspp_conv_kernel(
+// waves_per_eu(2, 3): without the upper bound hipcc caps the 128x128 configuration at 128 VGPRs (4 waves per
+// SIMD) and spills the prefetch registers to scratch inside the K loop
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(2, 3))) void aspp_conv_kernel(
     const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out, int B, int H, int W, int Cin,
     int Cout, int rate, int tps, long split_stride) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
