@@ -127,10 +127,13 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   __shared__ double acc[4 * TP];
   __shared__ int4 tcache[kCacheW * kCacheH];
   // 1-D grid in XCD-contiguous order: neighbouring tiles (overlapping scan windows) share an L2
+  // ... and the N sources of one tile are consecutive: they read the same depth / tgt lines and the same
+  // lines of the channel-interleaved trans and src ([.., 3N]), which then leave HBM once instead of N times
   const int blk = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y;
-  const int img = blk / (tiles_x * tiles_y);  // (s*N + i)*B + b
-  const int b = img % d.B, si = img / d.B, i = si % d.N, s = si / d.N;
+  const int i = blk % d.N, rest = blk / d.N;
+  const int tx = rest % tiles_x, ty = (rest / tiles_x) % tiles_y;
+  const int sbi = rest / (tiles_x * tiles_y), b = sbi % d.B, s = sbi / d.B;
+  const int img = (s * d.N + i) * d.B + b;
   const int HW = d.H * d.W, C3 = 3 * d.N;
   const int ng = d.N < 2 ? d.N : 2;
   const int4* __restrict__ stab = shift + (size_t)img * (tiles_x * tiles_y);
@@ -164,30 +167,61 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   float* __restrict__ ovf = Ovf + (size_t)img * HW * 4;
   bool flagged = false;
 
-  for (int k = threadIdx.x; k < n_all; k += kSplatThreads) {
-    int u, v;
-    bool scan;
+  // The scan loop is software pipelined by hand: the coalesced first stage (depth, translations, tgt) of
+  // the NEXT scanned pixel is in flight while this one is processed, and a home pixel's four source taps
+  // are requested before the LDS atomics and consumed after them.  (Half of a wave's life was spent parked
+  // on these two round trips.)
+  // pixel of scan step k: (u, v, scan); ok = false for the home-pass slots that do nothing
+  auto locate = [&](int k, int& u, int& v, bool& scan) -> bool {
     if (k < n_scan) {
       const int ly = (int)(((float)k + 0.5f) * inv_rw);
       u = sxl + (k - ly * RW);
       v = syl + ly;
       scan = true;
-    } else {  // home pixels the window does not cover (|shift| > reach)
-      const int kk = k - n_scan;
-      u = x0 + (kk & (STW - 1));
-      v = y0 + (kk / STW);
-      if (u >= x1 || v >= y1) continue;
-      if (u >= sxl && u < sxh && v >= syl && v < syh) continue;
-      scan = false;
+      return true;
     }
+    // home pixels the window does not cover (|shift| > reach)
+    const int kk = k - n_scan;
+    u = x0 + (kk & (STW - 1));
+    v = y0 + (kk / STW);
+    scan = false;
+    return u < x1 && v < y1 && !(u >= sxl && u < sxh && v >= syl && v < syh);
+  };
+  int nu = 0, nv = 0;
+  bool nscan = false, nok = false;
+  float ndep = 0.f;
+  f3 nt{0.f, 0.f, 0.f}, ntv{0.f, 0.f, 0.f};
+  auto fetch = [&](int k) {
+    nok = k < n_all && locate(k, nu, nv, nscan);
+    if (nok) {
+      const int p = nv * d.W + nu;
+      ndep = depth[sb + p];
+      nt = ld3(trans + (sb + p) * C3 + 3 * i);
+      ntv = ld3(tgt + (imgpix + p) * 3);
+    }
+  };
+  fetch(threadIdx.x);
+  for (int k = threadIdx.x; k < n_all; k += kSplatThreads) {
+    const int u = nu, v = nv;
+    const bool scan = nscan, ok = nok;
+    const float dep = ndep;
+    const f3 t = nt, tv = ntv;
+    fetch(k + kSplatThreads);
+    if (!ok) continue;
     const bool home = (u >= x0 && u < x1 && v >= y0 && v < y1);
     const int p = v * d.W + u;
-    const float dep = depth[sb + p];
-    const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
     const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, true, t.x, t.y, t.z);
     const Corners c = corners(g.x, g.y, xmax, ymax);
+    const bool do_gather = home && i < ng;
+    f3 ta{0.f, 0.f, 0.f}, tb = ta, tc = ta, td = ta;
+    if (do_gather) {  // the taps of the gather (utils.py:322-325): requested now, used after the atomics
+      const float* sbase = src + imgpix * C3 + 3 * i;
+      ta = ld3(sbase + (size_t)(c.y0 * d.W + c.x0) * C3);
+      tb = ld3(sbase + (size_t)(c.y1 * d.W + c.x0) * C3);
+      tc = ld3(sbase + (size_t)(c.y0 * d.W + c.x1) * C3);
+      td = ld3(sbase + (size_t)(c.y1 * d.W + c.x1) * C3);
+    }
     const SplatW sw = splat_weights(g.x, g.y, c, true, g.z);
-    const f3 tv = ld3(tgt + (imgpix + p) * 3);
     const int cx[4] = {c.x0, c.x0, c.x1, c.x1}, cy[4] = {c.y0, c.y1, c.y0, c.y1};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -234,17 +268,13 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
         flagged = true;
       }
     }
-    if (home && i < ng) {  // gather (utils.py:297-335)
-      const int i00 = c.y0 * d.W + c.x0, i01 = c.y1 * d.W + c.x0, i10 = c.y0 * d.W + c.x1, i11 = c.y1 * d.W + c.x1;
+    if (do_gather) {  // gather (utils.py:297-335)
       const float wx0 = c.fx1 - g.x, wx1 = g.x - c.fx0, wy0 = c.fy1 - g.y, wy1 = g.y - c.fy0;
       const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
-      const float* sbase = src + imgpix * C3 + 3 * i;
-      const f3 a = ld3(sbase + (size_t)i00 * C3), bb = ld3(sbase + (size_t)i01 * C3);
-      const f3 cc = ld3(sbase + (size_t)i10 * C3), dd = ld3(sbase + (size_t)i11 * C3);
       st3(G + ((((size_t)s * ng + i) * d.B + b) * HW + p) * 3,
-          ((w00 * a.x + w01 * bb.x) + w10 * cc.x) + w11 * dd.x,
-          ((w00 * a.y + w01 * bb.y) + w10 * cc.y) + w11 * dd.y,
-          ((w00 * a.z + w01 * bb.z) + w10 * cc.z) + w11 * dd.z);
+          ((w00 * ta.x + w01 * tb.x) + w10 * tc.x) + w11 * td.x,
+          ((w00 * ta.y + w01 * tb.y) + w10 * tc.y) + w11 * td.y,
+          ((w00 * ta.z + w01 * tb.z) + w10 * tc.z) + w11 * td.z);
     }
   }
   if (flagged) flags[img] = 1;
@@ -339,7 +369,8 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
 // 12-byte d_trans pieces of all sources are stored back to back, so each 128-byte line leaves L2 once).
 // grid: S*B*tiles blocks (1-D).  d_depth [S,B,H,W], d_trans [S,B,H,W,3N], dP partials [S][N*B][tiles][12].
 template <int N>
-__global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __restrict__ tgt,
+__global__ __launch_bounds__(kBlock)
+void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                const float* __restrict__ src,
                                                                const float* __restrict__ depth,
                                                                const float* __restrict__ trans,
@@ -377,56 +408,106 @@ __global__ __launch_bounds__(kBlock) void loss_warp_bwd_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < 12; ++k) dp[i][k] = 0.0f;
   }
+  // Memory-level parallelism is what bounds this kernel (every pixel needs a coalesced first stage -
+  // depth, tgt, translations - and then ~13 dependent gathers per source), so the loop is software
+  // pipelined by hand: the first stage of pixel it+1 is in flight while pixel it is processed, and the
+  // gathers of a PAIR of sources are all issued before the first of them is consumed.
+  float n_dep;
+  f3 n_tv, n_t[N];
+  auto fetch1 = [&](int it) {
+    const int k = it * kBlock + threadIdx.x;
+    const int u = min(x0 + (k & (BTW - 1)), d.W - 1), v = min(y0 + k / BTW, d.H - 1);  // clamped: always a valid address
+    const int p = v * d.W + u;
+    n_dep = depth[sb + p];
+    n_tv = ld3(tgt + (img + p) * 3);
+#pragma unroll
+    for (int i = 0; i < N; ++i) n_t[i] = ld3(trans + (sb + p) * C3 + 3 * i);
+  };
+  fetch1(0);
 #pragma unroll 1
   for (int it = 0; it < kLossPPT; ++it) {
     const int k = it * kBlock + threadIdx.x;
     const int u = x0 + (k & (BTW - 1)), v = y0 + k / BTW;
+    const float dep = n_dep;
+    const f3 tv = n_tv;
+    f3 tr[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) tr[i] = n_t[i];
+    if (it + 1 < kLossPPT) fetch1(it + 1);
     if (u >= d.W || v >= d.H) continue;
     const int p = v * d.W + u;
-    const float dep = depth[sb + p];
-    const f3 tv = ld3(tgt + (img + p) * 3);
     const float gxc = grid_coord(u, step_x, xmax), gyc = grid_coord(v, step_y, ymax);
     float ddsum = 0.0f;
     float dts[C3];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const size_t simg = ((size_t)s * N + i) * d.B + b;
-      // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
-      if (clr[i]) reinterpret_cast<float4*>(Ovf + simg * HW * 4)[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* hb = Hb + simg * HW * 4;  // part A; part B one plane further
-      const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
-      const Geom g = geom_fwd(ps[i], gxc, gyc, dep, true, t.x, t.y, t.z);
-      const Corners c = corners(g.x, g.y, xmax, ymax);
-      const int i00 = c.y0 * d.W + c.x0, i01 = c.y1 * d.W + c.x0, i10 = c.y0 * d.W + c.x1, i11 = c.y1 * d.W + c.x1;
-      float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
-      if (i < NG) {
-        const float wx0 = c.fx1 - g.x, wx1 = g.x - c.fx0, wy0 = c.fy1 - g.y, wy1 = g.y - c.fy0;
-        const float* sbase = src + img * C3 + 3 * i;
-        const f3 a = ld3(sbase + (size_t)i00 * C3), bb = ld3(sbase + (size_t)i01 * C3);
-        const f3 cc = ld3(sbase + (size_t)i10 * C3), dd = ld3(sbase + (size_t)i11 * C3);
-        const f3 go = ld3(dG + ((((size_t)s * NG + i) * d.B + b) * HW + p) * 3);
-        gx_ = gl * (go.x * (wy0 * (cc.x - a.x) + wy1 * (dd.x - bb.x)) + go.y * (wy0 * (cc.y - a.y) + wy1 * (dd.y - bb.y)) +
-                    go.z * (wy0 * (cc.z - a.z) + wy1 * (dd.z - bb.z)));
-        gy_ = gl * (go.x * (wx0 * (bb.x - a.x) + wx1 * (dd.x - cc.x)) + go.y * (wx0 * (bb.y - a.y) + wx1 * (dd.y - cc.y)) +
-                    go.z * (wx0 * (bb.z - a.z) + wx1 * (dd.z - cc.z)));
-      }
-      const SplatW sw = splat_weights(g.x, g.y, c, true, g.z);
-      const int idx[4] = {i00, i01, i10, i11};
-      float dgk[4];
+    for (int i0 = 0; i0 < N; i0 += 2) {
+      constexpr int kPair = 2;
+      Geom g[kPair];
+      Corners c[kPair];
+      int idx[kPair][4];
+      f3 ta[kPair][4], go[kPair];
+      float4 ha[kPair][4], hv[kPair][4];
+      // phase A: geometry of the pair, addresses of every gather
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 ha = *reinterpret_cast<const float4*>(hb + (size_t)idx[q] * 4);
-        const float4 hv = *reinterpret_cast<const float4*>(hb + hb_plane + (size_t)idx[q] * 4);
-        const float da = ((ha.x * tv.x + ha.y * tv.y) + ha.z * tv.z) - ha.w;
-        const float dv = ((hv.x * tv.x + hv.y * tv.y) + hv.z * tv.z) - hv.w;
-        dgk[q] = (gl * da + kv[i] * dv) * sw.g[q];
+      for (int j = 0; j < kPair; ++j) {
+        const int i = i0 + j;
+        if (i >= N) continue;
+        g[j] = geom_fwd(ps[i], gxc, gyc, dep, true, tr[i].x, tr[i].y, tr[i].z);
+        c[j] = corners(g[j].x, g[j].y, xmax, ymax);
+        idx[j][0] = c[j].y0 * d.W + c[j].x0; idx[j][1] = c[j].y1 * d.W + c[j].x0;
+        idx[j][2] = c[j].y0 * d.W + c[j].x1; idx[j][3] = c[j].y1 * d.W + c[j].x1;
       }
-      gx_ += -(dgk[0] + dgk[1]) * sw.dx0 + (dgk[2] + dgk[3]) * sw.dx1;
-      gy_ += -(dgk[0] + dgk[2]) * sw.dy0 + (dgk[1] + dgk[3]) * sw.dy1;
-      gz_ = -0.25f * sw.zin * ((dgk[0] + dgk[1]) + (dgk[2] + dgk[3]));
-      float dd_;
-      geom_bwd(ps[i], g, dep, true, t.x, t.y, t.z, gx_, gy_, gz_, dd_, dts[3 * i], dts[3 * i + 1], dts[3 * i + 2], dp[i]);
-      ddsum += dd_;
+      // phase B: all gathers of the pair in flight together
+#pragma unroll
+      for (int j = 0; j < kPair; ++j) {
+        const int i = i0 + j;
+        if (i >= N) continue;
+        const size_t simg = ((size_t)s * N + i) * d.B + b;
+        // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
+        if (clr[i]) reinterpret_cast<float4*>(Ovf + simg * HW * 4)[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* hb = Hb + simg * HW * 4;  // part A; part B one plane further
+        if (i < NG) {
+          const float* sbase = src + img * C3 + 3 * i;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ta[j][q] = ld3(sbase + (size_t)idx[j][q] * C3);
+          go[j] = ld3(dG + ((((size_t)s * NG + i) * d.B + b) * HW + p) * 3);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ha[j][q] = *reinterpret_cast<const float4*>(hb + (size_t)idx[j][q] * 4);
+          hv[j][q] = *reinterpret_cast<const float4*>(hb + hb_plane + (size_t)idx[j][q] * 4);
+        }
+      }
+      // phase C: chain rule
+#pragma unroll
+      for (int j = 0; j < kPair; ++j) {
+        const int i = i0 + j;
+        if (i >= N) continue;
+        float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
+        if (i < NG) {
+          const float wx0 = c[j].fx1 - g[j].x, wx1 = g[j].x - c[j].fx0, wy0 = c[j].fy1 - g[j].y, wy1 = g[j].y - c[j].fy0;
+          const f3 a = ta[j][0], bb = ta[j][1], cc = ta[j][2], dd = ta[j][3], gq = go[j];
+          gx_ = gl * (gq.x * (wy0 * (cc.x - a.x) + wy1 * (dd.x - bb.x)) + gq.y * (wy0 * (cc.y - a.y) + wy1 * (dd.y - bb.y)) +
+                      gq.z * (wy0 * (cc.z - a.z) + wy1 * (dd.z - bb.z)));
+          gy_ = gl * (gq.x * (wx0 * (bb.x - a.x) + wx1 * (dd.x - cc.x)) + gq.y * (wx0 * (bb.y - a.y) + wx1 * (dd.y - cc.y)) +
+                      gq.z * (wx0 * (bb.z - a.z) + wx1 * (dd.z - cc.z)));
+        }
+        const SplatW sw = splat_weights(g[j].x, g[j].y, c[j], true, g[j].z);
+        float dgk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float da = ((ha[j][q].x * tv.x + ha[j][q].y * tv.y) + ha[j][q].z * tv.z) - ha[j][q].w;
+          const float dv = ((hv[j][q].x * tv.x + hv[j][q].y * tv.y) + hv[j][q].z * tv.z) - hv[j][q].w;
+          dgk[q] = (gl * da + kv[i] * dv) * sw.g[q];
+        }
+        gx_ += -(dgk[0] + dgk[1]) * sw.dx0 + (dgk[2] + dgk[3]) * sw.dx1;
+        gy_ += -(dgk[0] + dgk[2]) * sw.dy0 + (dgk[1] + dgk[3]) * sw.dy1;
+        gz_ = -0.25f * sw.zin * ((dgk[0] + dgk[1]) + (dgk[2] + dgk[3]));
+        float dd_;
+        geom_bwd(ps[i], g[j], dep, true, tr[i].x, tr[i].y, tr[i].z, gx_, gy_, gz_, dd_, dts[3 * i], dts[3 * i + 1],
+                 dts[3 * i + 2], dp[i]);
+        ddsum += dd_;
+      }
     }
     d_depth[sb + p] = ddsum;
 #pragma unroll

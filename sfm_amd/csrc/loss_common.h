@@ -54,7 +54,10 @@ static inline StencilPlan stencil_plan(const LossDims& d, int rows_override) {
 #define SFM_STH 32
 #endif
 constexpr int STW = 64, STH = SFM_STH;  // splat: destination tile of one workgroup (LDS: 4 fp64 planes)
-constexpr int kSplatThreads = STW * STH / 4;  // 4 home pixels per thread
+#ifndef SFM_SPLAT_PPT
+#define SFM_SPLAT_PPT 4
+#endif
+constexpr int kSplatThreads = STW * STH / SFM_SPLAT_PPT;  // home pixels per thread
 constexpr int BTW = 64, BTH = 16;  // backward warp: pixel tile of one workgroup
 constexpr int kLossPPT = BTW * BTH / kBlock;  // pixels per thread in the backward warp kernel
 

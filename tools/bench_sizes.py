@@ -27,6 +27,15 @@ for label, B, H, W, S, N, city in CASES:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     units = B * H * W * S * N * 2
     nf, _ = eng.overflow_state()
+    import ctypes
+    from sfm_amd import _lib
+    lib = _lib.load(); st = (ctypes.c_float * 7)()
+    lib.sfm_prof_enable(1)
+    for _ in range(3):
+        step(); torch.cuda.synchronize(); lib.sfm_prof_read(st)
+    lib.sfm_prof_enable(0)
+    names = ["tile_shift", "warp_fwd", "stencil", "reduce", "finalize", "warp_bwd", "pose_grad"]
+    print("   stage us per Mpix-scale:", {n: round(v / 3 * 1e3 / (B * H * W * S / 1e6), 1) for n, v in zip(names, st)}, flush=True)
     print(f"{label}: {dt*1e3:.3f} ms/step  {units/dt/1e9:.2f} Gpix/s  step_frac_of_hbm_peak {130.0*units/dt/8e12:.3f}  "
           f"workspace {eng.ws.numel()*4/2**30:.2f} GiB  loss {float(out[0]):.5f}", flush=True)
     del eng, tgt, src, depth, trans, out
