@@ -132,6 +132,48 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
                       const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
                       float* d_pose, void* stream);
 
+/* ---- the prediction pyramid either side of the warp loop ----------------------
+ * All scales of a call go in one launch; the per-scale pointer / size arrays are HOST arrays read at call
+ * time (S, n_maps <= 16).  No exchange step: under data parallelism pass the global batch and sum the
+ * scalar over ranks.  Reductions run in a fixed order (reproducible).
+ *
+ * pred_disp = d / tf.reduce_mean(d, axis=[1,2,3], keep_dims=True), pred_depth = 1. / pred_disp
+ * (SfMLearner_uni.py:40, 47).  disp[s], disp_norm[s], depth[s]: [B, n[s]] (n = h*w*1); mean [S,B];
+ * ws: sfm_disp_normalize_workspace_floats(n, S, B) floats (chunk partial sums), undefined between calls. */
+long long sfm_disp_normalize_workspace_floats(const int* n, int S, int B);
+int sfm_disp_normalize_fwd(const float* const* disp, const int* n, int S, int B, float* const* disp_norm,
+                           float* const* depth, float* mean, float* ws, void* stream);
+/* g_disp_norm / g_depth (arrays or single entries may be NULL = zero) -> g_disp[s] [B, n[s]]. */
+int sfm_disp_normalize_bwd(const float* const* disp, const float* mean, const float* const* g_disp_norm,
+                           const float* const* g_depth, const int* n, int S, int B, float* const* g_disp, float* ws,
+                           void* stream);
+
+/* tf.image.resize_bilinear(x, [H, W]) with TF-1 defaults (align_corners=False), SfMLearner_uni.py:91, 113:
+ * in[s] [B,h[s],w[s],C] -> out [S,B,H,W,C], the stacked layout sfm_loss_forward reads (C = 1 for pred_depth,
+ * 3N for pred_exp_logits; C in {1,2,3,4,6,9,12}; h[s] <= H, w[s] <= W).  The adjoint is two separable gather
+ * passes (no atomics): gout [S,B,H,W,C] -> gin[s] [B,h[s],w[s],C], written, or added to gin[s] if accumulate;
+ * ws: sfm_pyramid_upsample_bwd_workspace_floats(...) floats (the row-reduced intermediate). */
+int sfm_pyramid_upsample_fwd(const float* const* in, const int* h, const int* w, int S, int B, int C, int H, int W,
+                             float* out, void* stream);
+long long sfm_pyramid_upsample_bwd_workspace_floats(const int* h, const int* w, int S, int B, int C, int H, int W);
+int sfm_pyramid_upsample_bwd(const float* gout, const int* h, const int* w, int S, int B, int C, int H, int W,
+                             int accumulate, float* const* gin, float* ws, void* stream);
+/* the same for one map */
+int sfm_resize_bilinear_fwd(const float* in, int B, int h, int w, int C, int H, int W, float* out, void* stream);
+int sfm_resize_bilinear_bwd(const float* gout, int B, int h, int w, int C, int H, int W, float* gin, float* ws,
+                            void* stream);
+
+/* smooth_loss of SfMLearner_uni.py:94-101 with compute_smooth_loss :205-219:
+ *   loss = sum_m  w_smooth[m] * compute_smooth_loss(maps[m]) + w_abs[m] * mean|maps[m]|
+ * maps[m] [B,h[m],w[m],c[m]] (h, w >= 3); every mean divides by the GLOBAL element count (B_global in
+ * place of B).  Value and gradient in one pass: d_maps (NULL, or per map NULL = not wanted) receives
+ * gscale * dloss/dmaps[m]; loss_out one float (this rank's share of the global mean).
+ * ws: sfm_smooth_workspace_floats(...) floats, contents undefined between calls. */
+long long sfm_smooth_workspace_floats(const int* h, const int* w, const int* c, int n_maps, int B);
+int sfm_smooth_loss(const float* const* maps, float* const* d_maps, const int* h, const int* w, const int* c,
+                    const float* w_smooth, const float* w_abs, int n_maps, int B, int B_global, float gscale, float* ws,
+                    float* loss_out, void* stream);
+
 /* ---- ASPP dilated 3x3 convolutions: nets.py:451-471 (disp_bottleneck_dense) --------------------
  * slim.conv2d(x, Cout, [3, 3], rate=rate) of nets.py:457, 458, 463 - the convolution itself,
  * without the arg-scope's batch norm / ELU - as fp32-input MFMA implicit GEMM, and its two

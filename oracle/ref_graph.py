@@ -395,6 +395,13 @@ def tf_ssim(img1, img2, cs_map=False, mean_metric=True, size=3, sigma=1.5):
 # ----------------------------------------------------------------------------
 # loss assembly: SfMLearner_uni.py:75-176, 205-219
 # ----------------------------------------------------------------------------
+def normalize_disp(pred_disp: Sequence[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
+    """SfMLearner_uni.py:40, 47: ``pred_disp = [d / tf.reduce_mean(d, axis=[1,2,3], keep_dims=True) ...]``,
+    ``pred_depth = [1. / d for d in pred_disp]``."""
+    dn = [d / d.mean(dim=(1, 2, 3), keepdim=True) for d in pred_disp]
+    return dn, [1.0 / d for d in dn]
+
+
 def resize_bilinear_tf1(x_nhwc: Tensor, out_h: int, out_w: int) -> Tensor:
     """``tf.image.resize_bilinear(x, [h, w])`` with TF-1 defaults (align_corners=False,
     no half-pixel centres): src = dst * in/out, top-left anchored.  ASSUMPTION"""

@@ -4,6 +4,7 @@ loss hot path of alncat/SFM, behind the reference's own function signatures.
     from sfm_amd.utils import projective_inverse_warp, projective_warp, \
         bilinear_sampler, bilinear_project, tf_ssim
     from sfm_amd.loss import multi_scale_loss
+    from sfm_amd.pyramid import normalize_disp, resize_bilinear, compute_smooth_loss
     from sfm_amd.aspp import dilated_conv3x3
 
 The compute lives in ``libsfm_amd.so`` (hand-written HIP, C ABI in include/sfm_amd.h);
@@ -14,11 +15,13 @@ from . import _lib  # noqa: F401
 from .utils import (bilinear_project, bilinear_sampler, cam2pixel, corner_indices, euler2mat, meshgrid,  # noqa: F401
                     pixel2cam, pose_vec2mat, project_coords, projective_inverse_warp, projective_warp, ssim_value,
                     tf_ssim)
-from .loss import compute_smooth_loss, multi_scale_loss, resize_bilinear  # noqa: F401
+from .loss import multi_scale_loss  # noqa: F401
+from .pyramid import compute_smooth_loss, normalize_disp, resize_bilinear  # noqa: F401
 from .aspp import dilated_conv3x3  # noqa: F401
 from ._lib import SfmAmdError  # noqa: F401
 
 __all__ = ["projective_inverse_warp", "projective_warp", "bilinear_sampler", "bilinear_project", "tf_ssim",
            "ssim_value", "pose_vec2mat", "euler2mat", "meshgrid", "pixel2cam", "cam2pixel", "project_coords",
-           "corner_indices", "multi_scale_loss", "compute_smooth_loss", "resize_bilinear", "dilated_conv3x3",
+           "corner_indices", "multi_scale_loss", "compute_smooth_loss", "resize_bilinear", "normalize_disp",
+           "dilated_conv3x3",
            "SfmAmdError"]

@@ -45,6 +45,16 @@ SIGNATURES = {
     "sfm_aspp_conv3x3_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv3x3_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv3x3_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_disp_normalize_workspace_floats": [_P, _I, _I],
+    "sfm_disp_normalize_fwd": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "sfm_disp_normalize_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "sfm_pyramid_upsample_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "sfm_pyramid_upsample_bwd_workspace_floats": [_P, _P, _I, _I, _I, _I, _I],
+    "sfm_pyramid_upsample_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_resize_bilinear_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "sfm_resize_bilinear_bwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_smooth_workspace_floats": [_P, _P, _P, _I, _I],
+    "sfm_smooth_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "sfm_prof_enable": [_I],
     "sfm_prof_stages": [],
     "sfm_prof_read": [_P],

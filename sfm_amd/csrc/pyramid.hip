@@ -1,0 +1,602 @@
+// The steps of build_train_graph either side of the warp loop that work on the prediction PYRAMID
+// (SURVEY.md section 8f rows 1-2), each for all scales in one launch:
+//
+//   sfm_disp_normalize_*    pred_disp = d / reduce_mean(d, [1,2,3]); pred_depth = 1 / pred_disp   SfMLearner_uni.py:40,47
+//   sfm_pyramid_upsample_*  tf.image.resize_bilinear(pred_depth[s] / pred_exp_logits[s], [H, W])   SfMLearner_uni.py:91,113
+//   sfm_smooth_loss         smooth_weight/2^s compute_smooth_loss(pred_disp[s]) + explain_reg_weight/2^s
+//                           (compute_smooth_loss(pred_exp_logits[s]) + mean|pred_exp_logits[s]|)   SfMLearner_uni.py:94-101, 205-219
+//
+// and their adjoints (implicit in the reference: tf.gradients, SfMLearner_uni.py:306).  None of them has an
+// exchange step: under data parallelism every mean is over the global batch (B_global in the denominators)
+// and the caller sums the scalar over ranks.  All reductions run in a fixed order: results are reproducible.
+//
+// The per-scale pointers and sizes of a call are copied from the caller's host arrays into the kernel
+// arguments (<= kMaxMaps maps), so no device-side table has to be built.
+#include "sfm_device.h"
+#include "sfm_internal.h"
+
+namespace sfm {
+namespace {
+
+constexpr int kMaxMaps = 16;
+constexpr int kMaxC = 12;  // 3 * (at most 4 sources)
+
+// ------------------------------------------------------------------ disp normalisation
+// Two launches per direction, both over chunks of kNormChunk elements of one (scale, batch item): per-chunk
+// partial sums (fixed order within a chunk), then every chunk's workgroup adds up its item's partials in the
+// same fixed order and applies the result - no atomics, no single-workgroup-per-item bottleneck.
+struct NormArgs {
+  const float* disp[kMaxMaps];
+  float* dispn[kMaxMaps];
+  float* depth[kMaxMaps];
+  const float* g_dispn[kMaxMaps];
+  const float* g_depth[kMaxMaps];
+  float* g_disp[kMaxMaps];
+  int n[kMaxMaps];      // h*w*1 per batch item
+  int chunk0[kMaxMaps + 1];  // first chunk of each scale; a scale has B * chunks(s) chunks, item-major
+  int S, B;
+};
+constexpr int kNormChunk = 4096;  // elements per workgroup (16 per thread)
+
+struct NormItem {
+  int s, b, chunk, nchunk, n;
+};
+__device__ __forceinline__ NormItem norm_item(const NormArgs& a, int blk) {
+  NormItem it;
+  it.s = 0;
+  while (it.s + 1 < a.S && blk >= a.chunk0[it.s + 1]) ++it.s;
+  it.n = a.n[it.s];
+  it.nchunk = (it.n + kNormChunk - 1) / kNormChunk;
+  const int r = blk - a.chunk0[it.s];
+  it.b = r / it.nchunk;
+  it.chunk = r - it.b * it.nchunk;
+  return it;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // red may still be read from a previous use
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// sum of the item's chunk partials, the same order in every thread of every workgroup of the item
+__device__ __forceinline__ float item_total(const float* __restrict__ part, int first, int nchunk) {
+  float t = 0.f;
+  for (int k = 0; k < nchunk; ++k) t += part[first + k];
+  return t;
+}
+
+// MODE 0: part[chunk] = sum d.   MODE 1: part[chunk] = sum t d  with t = g_dispn - g_depth / u^2, u = d / mean
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void disp_partial_kernel(NormArgs a, const float* __restrict__ mean,
+                                                              float* __restrict__ part) {
+  __shared__ float red[4];
+  const NormItem it = norm_item(a, blockIdx.x);
+  const size_t base = (size_t)it.b * it.n;
+  const float* __restrict__ d = a.disp[it.s] + base;
+  const int k0 = it.chunk * kNormChunk, k1 = min(k0 + kNormChunk, it.n);
+  float acc = 0.f;
+  if (MODE == 0) {
+    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) acc += d[k];
+  } else {
+    const float m = mean[it.s * a.B + it.b];
+    const float* __restrict__ gu = a.g_dispn[it.s] ? a.g_dispn[it.s] + base : nullptr;
+    const float* __restrict__ gd = a.g_depth[it.s] ? a.g_depth[it.s] + base : nullptr;
+    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+      float t = gu ? gu[k] : 0.f;
+      if (gd) {
+        const float u = d[k] / m;
+        t -= gd[k] / (u * u);
+      }
+      acc += t * d[k];
+    }
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void disp_normalize_fwd_kernel(NormArgs a, const float* __restrict__ part,
+                                                                    float* __restrict__ mean) {
+  const NormItem it = norm_item(a, blockIdx.x);
+  const float m = item_total(part, blockIdx.x - it.chunk, it.nchunk) / (float)it.n;
+  if (it.chunk == 0 && threadIdx.x == 0) mean[it.s * a.B + it.b] = m;
+  const size_t base = (size_t)it.b * it.n;
+  const float* __restrict__ d = a.disp[it.s] + base;
+  float* __restrict__ dn = a.dispn[it.s] + base;
+  float* __restrict__ dp = a.depth[it.s] + base;
+  const int k0 = it.chunk * kNormChunk, k1 = min(k0 + kNormChunk, it.n);
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+    const float q = d[k] / m;
+    dn[k] = q;
+    dp[k] = 1.0f / q;
+  }
+}
+
+// u = d / m, depth = 1 / u.  With t_k = g_dispn_k - g_depth_k / u_k^2 (dL/du_k):
+//   dL/dd_k = t_k / m - (sum_j t_j d_j) / (m^2 n)
+__global__ __launch_bounds__(kBlock) void disp_normalize_bwd_kernel(NormArgs a, const float* __restrict__ part,
+                                                                    const float* __restrict__ mean) {
+  const NormItem it = norm_item(a, blockIdx.x);
+  const float m = mean[it.s * a.B + it.b];
+  const float corr = item_total(part, blockIdx.x - it.chunk, it.nchunk) / ((m * m) * (float)it.n);
+  const size_t base = (size_t)it.b * it.n;
+  const float* __restrict__ d = a.disp[it.s] + base;
+  const float* __restrict__ gu = a.g_dispn[it.s] ? a.g_dispn[it.s] + base : nullptr;
+  const float* __restrict__ gd = a.g_depth[it.s] ? a.g_depth[it.s] + base : nullptr;
+  float* __restrict__ g = a.g_disp[it.s] + base;
+  const int k0 = it.chunk * kNormChunk, k1 = min(k0 + kNormChunk, it.n);
+  for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+    float t = gu ? gu[k] : 0.f;
+    if (gd) {
+      const float u = d[k] / m;
+      t -= gd[k] / (u * u);
+    }
+    g[k] = t / m - corr;
+  }
+}
+
+// ------------------------------------------------------------------ bilinear upsample of the pyramid
+// tf.image.resize_bilinear, TF-1 defaults (align_corners=False, no half-pixel centres), resize_bilinear_op.cc:
+//   scale = in / (float)out;  src = dst * scale;  lo = floor(src);  hi = min(lo + 1, in - 1);  lerp = src - lo
+//   top = tl + (tr - tl) * xl;  bot = bl + (br - bl) * xl;  out = top + (bot - top) * yl
+struct Lerp {
+  int lo, hi;
+  float l;
+};
+__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_n) {
+  const float src = (float)dst * scale;
+  const float f = floorf(src);
+  Lerp o;
+  o.lo = min((int)f, in_n - 1);
+  o.hi = min(o.lo + 1, in_n - 1);
+  o.l = src - f;
+  return o;
+}
+
+struct PyrArgs {
+  const float* in[kMaxMaps];
+  float* gin[kMaxMaps];
+  int h[kMaxMaps], w[kMaxMaps];
+  int blk0[kMaxMaps + 1];  // first block of each scale (1-D grid)
+  long tmp0[kMaxMaps + 1]; // backward: first pixel of each scale's [B,H,w] intermediate
+  float sy[kMaxMaps], sx[kMaxMaps];
+  int S, B, C, H, W, accumulate;
+};
+
+__device__ __forceinline__ int scale_of_block(const PyrArgs& a, int blk) {
+  int s = 0;
+  while (s + 1 < a.S && blk >= a.blk0[s + 1]) ++s;
+  return s;
+}
+
+// one thread per output pixel, all C channels.  out [S,B,H,W,C].
+template <int C>
+__global__ __launch_bounds__(kBlock) void pyramid_upsample_fwd_kernel(PyrArgs a, float* __restrict__ out) {
+  const int s = scale_of_block(a, blockIdx.x);
+  const long k = (long)(blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
+  const long npx = (long)a.B * a.H * a.W;
+  if (k >= npx) return;
+  const int X = (int)(k % a.W), Y = (int)((k / a.W) % a.H), b = (int)(k / ((long)a.W * a.H));
+  const int h = a.h[s], w = a.w[s];
+  const float* __restrict__ in = a.in[s] + (size_t)b * h * w * C;
+  float* __restrict__ o = out + ((size_t)s * npx + k) * C;
+  if (h == a.H && w == a.W) {  // tf.image.resize_bilinear at the same size is the identity
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = in[((size_t)Y * w + X) * C + c];
+    return;
+  }
+  const Lerp ly = lerp_of(Y, a.sy[s], h), lx = lerp_of(X, a.sx[s], w);
+  const float* tl = in + ((size_t)ly.lo * w + lx.lo) * C;
+  const float* tr = in + ((size_t)ly.lo * w + lx.hi) * C;
+  const float* bl = in + ((size_t)ly.hi * w + lx.lo) * C;
+  const float* br = in + ((size_t)ly.hi * w + lx.hi) * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float top = tl[c] + (tr[c] - tl[c]) * lx.l;
+    const float bot = bl[c] + (br[c] - bl[c]) * lx.l;
+    o[c] = top + (bot - top) * ly.l;
+  }
+}
+
+// Adjoint (ResizeBilinearGrad) as two separable GATHER passes - the upsample is R_y (x) R_x, so its adjoint
+// is R_x^T then R_y^T - with no atomics and a fixed summation order:
+//   pass 1   tmp[b, Y, x, :] = sum_X  wx(X -> x) gout[b, Y, X, :]     one thread per (b, Y, x)
+//   pass 2   gin[b, y, x, :] (+)= sum_Y  wy(Y -> y) tmp[b, Y, x, :]   one thread per (b, y, x)
+// where wx(X -> x) = (1 - xl) if lo(X) == x, plus xl if hi(X) == x.  The candidate output columns / rows of an
+// input one are bracketed generously and each is tested with the forward's own arithmetic (lerp_of), so the
+// two directions can never disagree about which taps a pixel has.  A scale at full size is copied by pass 1.
+template <int C>
+__global__ __launch_bounds__(kBlock) void pyramid_upsample_bwd_x_kernel(PyrArgs a, const float* __restrict__ gout,
+                                                                        float* __restrict__ tmp) {
+  const int s = scale_of_block(a, blockIdx.x);
+  const int h = a.h[s], w = a.w[s];
+  const long k = (long)(blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
+  if (k >= (long)a.B * a.H * w) return;
+  const int x = (int)(k % w), Y = (int)((k / w) % a.H), b = (int)(k / ((long)w * a.H));
+  const long npx = (long)a.B * a.H * a.W;
+  const float* __restrict__ g = gout + ((size_t)s * npx + ((size_t)b * a.H + Y) * a.W) * C;
+  float acc[C];
+  if (h == a.H && w == a.W) {  // identity scale: straight to the output (pass 2 skips it)
+    float* __restrict__ o = a.gin[s] + (size_t)k * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = a.accumulate ? o[c] + g[(size_t)x * C + c] : g[(size_t)x * C + c];
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  const float rx = (float)a.W / (float)w;
+  const int X0 = max((int)floorf((float)(x - 1) * rx) - 1, 0), X1 = min((int)ceilf((float)(x + 1) * rx) + 1, a.W - 1);
+  for (int X = X0; X <= X1; ++X) {
+    const Lerp lx = lerp_of(X, a.sx[s], w);
+    if (lx.lo != x && lx.hi != x) continue;
+    const float wx = (lx.lo == x ? 1.0f - lx.l : 0.0f) + (lx.hi == x ? lx.l : 0.0f);
+    const float* gp = g + (size_t)X * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] += gp[c] * wx;
+  }
+  float* __restrict__ o = tmp + (a.tmp0[s] + (size_t)k) * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c] = acc[c];
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void pyramid_upsample_bwd_y_kernel(PyrArgs a, const float* __restrict__ tmp) {
+  const int s = scale_of_block(a, blockIdx.x);
+  const int h = a.h[s], w = a.w[s];
+  if (h == a.H && w == a.W) return;
+  const long k = (long)(blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
+  if (k >= (long)a.B * h * w) return;
+  const int x = (int)(k % w), y = (int)((k / w) % h), b = (int)(k / ((long)w * h));
+  const float* __restrict__ t = tmp + (a.tmp0[s] + (size_t)b * a.H * w + x) * C;
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  const float ry = (float)a.H / (float)h;
+  const int Y0 = max((int)floorf((float)(y - 1) * ry) - 1, 0), Y1 = min((int)ceilf((float)(y + 1) * ry) + 1, a.H - 1);
+  for (int Y = Y0; Y <= Y1; ++Y) {
+    const Lerp ly = lerp_of(Y, a.sy[s], h);
+    if (ly.lo != y && ly.hi != y) continue;
+    const float wy = (ly.lo == y ? 1.0f - ly.l : 0.0f) + (ly.hi == y ? ly.l : 0.0f);
+    const float* tp = t + (size_t)Y * w * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] += tp[c] * wy;
+  }
+  float* __restrict__ o = a.gin[s] + (size_t)k * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c] = a.accumulate ? o[c] + acc[c] : acc[c];
+}
+
+// ------------------------------------------------------------------ smoothness + |t| regulariser
+// compute_smooth_loss (SfMLearner_uni.py:205-219), forward differences:
+//   dx = p[:, :, 1:] - p[:, :, :-1]      dy = p[:, 1:] - p[:, :-1]
+//   dx2 = dx[:, :, 1:] - dx[:, :, :-1]   dxdy = dx[:, 1:] - dx[:, :-1]
+//   dydx = dy[:, :, 1:] - dy[:, :, :-1]  dy2 = dy[:, 1:] - dy[:, :-1]
+//   0.25 (mean|dx| + mean|dy|) + 0.75 (mean|dx2| + mean|dxdy| + mean|dydx| + mean|dy2|)
+// Every coefficient of the loss is known up front, so the value (7 sums per map) and the gradient come out of
+// one pass: a thread owns one element, evaluates the 18 differences it takes part in (each with the
+// forward's own fp32 arithmetic, so the signs agree with autodiff of the rounded values) and the 6 terms
+// anchored at it.
+struct SmoothArgs {
+  const float* map[kMaxMaps];
+  float* grad[kMaxMaps];  // may be null
+  int h[kMaxMaps], w[kMaxMaps], c[kMaxMaps];
+  int blk0[kMaxMaps + 1];
+  float w_smooth[kMaxMaps], w_abs[kMaxMaps];
+  int n_maps, B;
+  double b_global;
+  float gscale;
+};
+constexpr int kSmoothTerms = 7;  // |dx|, |dy|, |dx2|, |dxdy|, |dydx|, |dy2|, |p|
+
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
+
+constexpr int kSmoothPerThread = 8;
+constexpr int kSmoothPerBlock = kBlock * kSmoothPerThread;
+
+__global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, float* __restrict__ blockp) {
+  __shared__ float red[4 * kSmoothTerms];
+  int m = 0;
+  while (m + 1 < a.n_maps && (int)blockIdx.x >= a.blk0[m + 1]) ++m;
+  const unsigned h = a.h[m], w = a.w[m], C = a.c[m];
+  const unsigned total = (unsigned)a.B * h * w * C;  // < 2^31 (checked on the host)
+  const double bg = a.b_global;
+  const float ws = a.w_smooth[m];
+  const float k1x = (float)(0.25 * ws / (bg * h * (w - 1) * C)), k1y = (float)(0.25 * ws / (bg * (h - 1) * w * C));
+  const float k2xx = (float)(0.75 * ws / (bg * h * (w - 2) * C)), k2yy = (float)(0.75 * ws / (bg * (h - 2) * w * C));
+  const float k2xy = (float)(0.75 * ws / (bg * (h - 1) * (w - 1) * C));
+  const float kab = (float)(a.w_abs[m] / (bg * h * w * C));
+  const float* __restrict__ map = a.map[m];
+  float* __restrict__ grad = a.grad[m];
+  float t[kSmoothTerms];
+#pragma unroll
+  for (int j = 0; j < kSmoothTerms; ++j) t[j] = 0.f;
+#pragma unroll 2
+  for (int it = 0; it < kSmoothPerThread; ++it) {
+    const unsigned k = (blockIdx.x - a.blk0[m]) * kSmoothPerBlock + it * kBlock + threadIdx.x;
+    if (k >= total) break;
+    const unsigned pix = k / C, c = k - pix * C, row = pix / w, x = pix - row * w, y = row % h;
+    const int xi = (int)x, yi = (int)y, wi = (int)w, hi = (int)h;
+    // the 13 samples every difference below is made of: row y at x-2..x+2, column x at y-2..y+2 and the
+    // four diagonal neighbours; clamped addresses (a clamped sample is never used: see the range tests)
+    const float* __restrict__ p = map + (size_t)(k - (y * w + x) * C - c) + c;  // channel c of the batch item
+    auto P = [&](int dy, int dx) {
+      const int yy = min(max(yi + dy, 0), hi - 1), xx = min(max(xi + dx, 0), wi - 1);
+      return p[((size_t)yy * w + xx) * C];
+    };
+    const float p00 = P(0, 0), pm2 = P(0, -2), pm1 = P(0, -1), pp1 = P(0, 1), pp2 = P(0, 2);
+    const float qm2 = P(-2, 0), qm1 = P(-1, 0), qp1 = P(1, 0), qp2 = P(2, 0);
+    const float dmm = P(-1, -1), dmp = P(-1, 1), dpm = P(1, -1), dpp = P(1, 1);
+    // first differences, named by their anchor relative to (y, x): dx_ab = DX(y + a, x + b) = P(.., +1) - P(..)
+    const float dx_0m2 = pm1 - pm2, dx_0m1 = p00 - pm1, dx_00 = pp1 - p00, dx_0p1 = pp2 - pp1;
+    const float dx_p1m1 = qp1 - dpm, dx_p10 = dpp - qp1, dx_m1m1 = qm1 - dmm, dx_m10 = dmp - qm1;
+    const float dy_m20 = qm1 - qm2, dy_m10 = p00 - qm1, dy_00 = qp1 - p00, dy_p10 = qp2 - qp1;
+    const float dy_0m1 = dpm - pm1, dy_0p1 = dpp - pp1, dy_m1m1 = pm1 - dmm, dy_m1p1 = pp1 - dmp;
+    const bool xa = xi <= wi - 2, xb = xi >= 1, ya = yi <= hi - 2, yb = yi >= 1;
+    float g = kab * sgnf(p00);
+    t[6] += fabsf(p00);
+    if (xa) { t[0] += fabsf(dx_00); g -= k1x * sgnf(dx_00); }
+    if (xb) g += k1x * sgnf(dx_0m1);
+    if (ya) { t[1] += fabsf(dy_00); g -= k1y * sgnf(dy_00); }
+    if (yb) g += k1y * sgnf(dy_m10);
+    if (xi <= wi - 3) { const float v = dx_0p1 - dx_00; t[2] += fabsf(v); g += k2xx * sgnf(v); }   // dx2 anchored at x
+    if (xb && xa) g -= 2.0f * k2xx * sgnf(dx_00 - dx_0m1);                                          // ... at x-1
+    if (xi >= 2) g += k2xx * sgnf(dx_0m1 - dx_0m2);                                                 // ... at x-2
+    if (yi <= hi - 3) { const float v = dy_p10 - dy_00; t[5] += fabsf(v); g += k2yy * sgnf(v); }    // dy2
+    if (yb && ya) g -= 2.0f * k2yy * sgnf(dy_00 - dy_m10);
+    if (yi >= 2) g += k2yy * sgnf(dy_m10 - dy_m20);
+    if (ya && xa) {  // dxdy = DX(y+1, x) - DX(y, x), dydx = DY(y, x+1) - DY(y, x): equal in exact arithmetic only
+      const float v1 = dx_p10 - dx_00, v2 = dy_0p1 - dy_00;
+      t[3] += fabsf(v1); t[4] += fabsf(v2);
+      g += k2xy * (sgnf(v1) + sgnf(v2));
+    }
+    if (ya && xb) g -= k2xy * (sgnf(dx_p1m1 - dx_0m1) + sgnf(dy_00 - dy_0m1));    // anchored at (y, x-1)
+    if (yb && xa) g -= k2xy * (sgnf(dx_00 - dx_m10) + sgnf(dy_m1p1 - dy_m10));    // anchored at (y-1, x)
+    if (yb && xb) g += k2xy * (sgnf(dx_0m1 - dx_m1m1) + sgnf(dy_m10 - dy_m1m1));  // anchored at (y-1, x-1)
+    if (grad) grad[k] = a.gscale * g;
+  }
+  block_sum_store<kSmoothTerms>(t, red, blockp + (size_t)blockIdx.x * kSmoothTerms);
+}
+
+// one workgroup of 16 waves: wave v sums the block partials of the (map, term) pairs v, v+16, ... (lanes stride
+// over the blocks, then a shuffle tree: a fixed order), thread 0 combines the <= 112 sums in fp64
+constexpr int kSmoothReduceThreads = 1024;
+__global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(SmoothArgs a, const float* __restrict__ blockp,
+                                                                             float* __restrict__ loss_out) {
+  __shared__ double psum[kMaxMaps * kSmoothTerms];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npair = a.n_maps * kSmoothTerms;
+  for (int pr = wave; pr < npair; pr += kSmoothReduceThreads / 64) {
+    const int m = pr / kSmoothTerms, j = pr - m * kSmoothTerms;
+    double acc = 0.0;
+    for (int k = a.blk0[m] + lane; k < a.blk0[m + 1]; k += 64) acc += (double)blockp[(size_t)k * kSmoothTerms + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) psum[pr] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double total = 0.0;
+    for (int m = 0; m < a.n_maps; ++m) {
+      const double h = a.h[m], w = a.w[m], C = a.c[m], bg = a.b_global;
+      const double den[kSmoothTerms] = {bg * h * (w - 1) * C, bg * (h - 1) * w * C, bg * h * (w - 2) * C,
+                                        bg * (h - 1) * (w - 1) * C, bg * (h - 1) * (w - 1) * C, bg * (h - 2) * w * C,
+                                        bg * h * w * C};
+      const double ws = a.w_smooth[m];
+      const double coef[kSmoothTerms] = {0.25 * ws, 0.25 * ws, 0.75 * ws, 0.75 * ws, 0.75 * ws, 0.75 * ws, a.w_abs[m]};
+      for (int j = 0; j < kSmoothTerms; ++j) total += coef[j] * psum[m * kSmoothTerms + j] / den[j];
+    }
+    *loss_out = (float)total;
+  }
+}
+
+static inline int blocks_for(long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+// mode: grid over 0 = output pixels [B,H,W], 1 = the backward intermediate [B,H,w_s], 2 = input pixels [B,h_s,w_s]
+static int fill_pyr(PyrArgs& a, const int* h, const int* w, int S, int B, int C, int H, int W, int mode) {
+  if (!h || !w || S < 1 || S > kMaxMaps || B < 1 || H < 1 || W < 1 || C < 1 || C > kMaxC) return SFM_ERR_ARG;
+  if (!sfm_fits(H, W, C)) return SFM_ERR_TOO_LARGE;
+  a.S = S; a.B = B; a.C = C; a.H = H; a.W = W;
+  long blk = 0;
+  for (int s = 0; s < S; ++s) {
+    if (h[s] < 1 || w[s] < 1 || h[s] > H || w[s] > W) return SFM_ERR_ARG;  // the pyramid is only ever upsampled
+    a.h[s] = h[s]; a.w[s] = w[s];
+    a.sy[s] = (float)h[s] / (float)H;  // CalculateResizeScale: in / static_cast<float>(out)
+    a.sx[s] = (float)w[s] / (float)W;
+    a.blk0[s] = (int)blk;
+    blk += blocks_for(mode == 0 ? (long)B * H * W : (mode == 1 ? (long)B * H * w[s] : (long)B * h[s] * w[s]));
+    if (blk > 2147483647L) return SFM_ERR_TOO_LARGE;
+  }
+  a.blk0[S] = (int)blk;
+  long t = 0;
+  for (int s = 0; s < S; ++s) {
+    a.tmp0[s] = t;
+    if (h[s] != H || w[s] != W) t += (long)B * H * w[s];  // a scale at full size needs no intermediate
+  }
+  a.tmp0[S] = t;
+  a.accumulate = 0;
+  return SFM_OK;
+}
+
+}  // namespace
+}  // namespace sfm
+
+using namespace sfm;
+
+#define SFM_DISPATCH_C(C, KERNEL, ...)                                                  \
+  switch (C) {                                                                          \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                          \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                          \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                          \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                          \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                          \
+    case 9: hipLaunchKernelGGL(KERNEL<9>, __VA_ARGS__); break;                          \
+    case 12: hipLaunchKernelGGL(KERNEL<12>, __VA_ARGS__); break;                        \
+    default: return SFM_ERR_ARG;                                                        \
+  }
+
+extern "C" int sfm_pyramid_upsample_fwd(const float* const* in, const int* h, const int* w, int S, int B, int C, int H,
+                                        int W, float* out, void* stream) {
+  PyrArgs a;
+  const int rc = fill_pyr(a, h, w, S, B, C, H, W, 0);
+  if (rc) return rc;
+  if (!in || !out) return SFM_ERR_ARG;
+  for (int s = 0; s < S; ++s) {
+    if (!in[s]) return SFM_ERR_ARG;
+    a.in[s] = in[s];
+    a.gin[s] = nullptr;
+  }
+  SFM_DISPATCH_C(C, pyramid_upsample_fwd_kernel, dim3((unsigned)a.blk0[S]), dim3(kBlock), 0, (hipStream_t)stream, a, out)
+  return sfm_last_error();
+}
+
+extern "C" long long sfm_pyramid_upsample_bwd_workspace_floats(const int* h, const int* w, int S, int B, int C, int H,
+                                                               int W) {
+  PyrArgs a;
+  const int rc = fill_pyr(a, h, w, S, B, C, H, W, 1);
+  if (rc) return rc;
+  return (long long)a.tmp0[S] * C + 4;
+}
+
+extern "C" int sfm_pyramid_upsample_bwd(const float* gout, const int* h, const int* w, int S, int B, int C, int H, int W,
+                                        int accumulate, float* const* gin, float* ws, void* stream) {
+  PyrArgs a;
+  int rc = fill_pyr(a, h, w, S, B, C, H, W, 1);
+  if (rc) return rc;
+  if (!gin || !gout || !ws) return SFM_ERR_ARG;
+  for (int s = 0; s < S; ++s) {
+    if (!gin[s]) return SFM_ERR_ARG;
+    a.in[s] = nullptr;
+    a.gin[s] = gin[s];
+  }
+  a.accumulate = accumulate != 0;
+  SFM_DISPATCH_C(C, pyramid_upsample_bwd_x_kernel, dim3((unsigned)a.blk0[S]), dim3(kBlock), 0, (hipStream_t)stream, a, gout, ws)
+  PyrArgs a2 = a;
+  rc = fill_pyr(a2, h, w, S, B, C, H, W, 2);
+  if (rc) return rc;
+  for (int s = 0; s < S; ++s) a2.gin[s] = gin[s];
+  a2.accumulate = accumulate != 0;
+  SFM_DISPATCH_C(C, pyramid_upsample_bwd_y_kernel, dim3((unsigned)a2.blk0[S]), dim3(kBlock), 0, (hipStream_t)stream, a2, ws)
+  return sfm_last_error();
+}
+
+extern "C" int sfm_resize_bilinear_fwd(const float* in, int B, int h, int w, int C, int H, int W, float* out, void* stream) {
+  return sfm_pyramid_upsample_fwd(&in, &h, &w, 1, B, C, H, W, out, stream);
+}
+
+extern "C" int sfm_resize_bilinear_bwd(const float* gout, int B, int h, int w, int C, int H, int W, float* gin, float* ws,
+                                       void* stream) {
+  return sfm_pyramid_upsample_bwd(gout, &h, &w, 1, B, C, H, W, 0, &gin, ws, stream);
+}
+
+static int fill_norm(NormArgs& a, const float* const* disp, const int* n, int S, int B) {
+  if (!disp || !n || S < 1 || S > kMaxMaps || B < 1) return SFM_ERR_ARG;
+  long chunk = 0;
+  for (int s = 0; s < S; ++s) {
+    if (!disp[s] || n[s] < 1) return SFM_ERR_ARG;
+    a.disp[s] = disp[s];
+    a.n[s] = n[s];
+    a.dispn[s] = a.depth[s] = a.g_disp[s] = nullptr;
+    a.g_dispn[s] = a.g_depth[s] = nullptr;
+    a.chunk0[s] = (int)chunk;
+    chunk += (long)B * ((n[s] + kNormChunk - 1) / kNormChunk);
+    if (chunk > 2147483647L) return SFM_ERR_TOO_LARGE;
+  }
+  a.chunk0[S] = (int)chunk;
+  a.S = S;
+  a.B = B;
+  return SFM_OK;
+}
+
+extern "C" long long sfm_disp_normalize_workspace_floats(const int* n, int S, int B) {
+  if (!n || S < 1 || S > kMaxMaps || B < 1) return SFM_ERR_ARG;
+  long chunk = 0;
+  for (int s = 0; s < S; ++s) {
+    if (n[s] < 1) return SFM_ERR_ARG;
+    chunk += (long)B * ((n[s] + kNormChunk - 1) / kNormChunk);
+  }
+  return chunk;
+}
+
+extern "C" int sfm_disp_normalize_fwd(const float* const* disp, const int* n, int S, int B, float* const* disp_norm,
+                                      float* const* depth, float* mean, float* ws, void* stream) {
+  NormArgs a;
+  const int rc = fill_norm(a, disp, n, S, B);
+  if (rc) return rc;
+  if (!disp_norm || !depth || !mean || !ws) return SFM_ERR_ARG;
+  for (int s = 0; s < S; ++s) {
+    if (!disp_norm[s] || !depth[s]) return SFM_ERR_ARG;
+    a.dispn[s] = disp_norm[s];
+    a.depth[s] = depth[s];
+  }
+  const dim3 grid((unsigned)a.chunk0[S]);
+  hipLaunchKernelGGL(disp_partial_kernel<0>, grid, dim3(kBlock), 0, (hipStream_t)stream, a, (const float*)nullptr, ws);
+  hipLaunchKernelGGL(disp_normalize_fwd_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a, ws, mean);
+  return sfm_last_error();
+}
+
+extern "C" int sfm_disp_normalize_bwd(const float* const* disp, const float* mean, const float* const* g_disp_norm,
+                                      const float* const* g_depth, const int* n, int S, int B, float* const* g_disp,
+                                      float* ws, void* stream) {
+  NormArgs a;
+  const int rc = fill_norm(a, disp, n, S, B);
+  if (rc) return rc;
+  if (!mean || !g_disp || !ws) return SFM_ERR_ARG;
+  for (int s = 0; s < S; ++s) {
+    if (!g_disp[s]) return SFM_ERR_ARG;
+    a.g_disp[s] = g_disp[s];
+    a.g_dispn[s] = g_disp_norm ? g_disp_norm[s] : nullptr;
+    a.g_depth[s] = g_depth ? g_depth[s] : nullptr;
+  }
+  const dim3 grid((unsigned)a.chunk0[S]);
+  hipLaunchKernelGGL(disp_partial_kernel<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, a, mean, ws);
+  hipLaunchKernelGGL(disp_normalize_bwd_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a, ws, mean);
+  return sfm_last_error();
+}
+
+static int fill_smooth(SmoothArgs& a, const int* h, const int* w, const int* c, int n_maps, int B) {
+  if (!h || !w || !c || n_maps < 1 || n_maps > kMaxMaps || B < 1) return SFM_ERR_ARG;
+  long blk = 0;
+  for (int m = 0; m < n_maps; ++m) {
+    if (h[m] < 3 || w[m] < 3 || c[m] < 1) return SFM_ERR_ARG;  // the second differences need three samples per axis
+    a.h[m] = h[m]; a.w[m] = w[m]; a.c[m] = c[m];
+    a.blk0[m] = (int)blk;
+    const long nel = (long)B * h[m] * w[m] * c[m];
+    if (nel > 2147483647L) return SFM_ERR_TOO_LARGE;
+    blk += (nel + kSmoothPerBlock - 1) / kSmoothPerBlock;
+  }
+  a.blk0[n_maps] = (int)blk;
+  a.n_maps = n_maps;
+  a.B = B;
+  return SFM_OK;
+}
+
+extern "C" long long sfm_smooth_workspace_floats(const int* h, const int* w, const int* c, int n_maps, int B) {
+  SmoothArgs a;
+  const int rc = fill_smooth(a, h, w, c, n_maps, B);
+  if (rc) return rc;
+  return (long long)a.blk0[n_maps] * kSmoothTerms;
+}
+
+extern "C" int sfm_smooth_loss(const float* const* maps, float* const* d_maps, const int* h, const int* w, const int* c,
+                               const float* w_smooth, const float* w_abs, int n_maps, int B, int B_global, float gscale,
+                               float* ws, float* loss_out, void* stream) {
+  SmoothArgs a;
+  const int rc = fill_smooth(a, h, w, c, n_maps, B);
+  if (rc) return rc;
+  if (!maps || !w_smooth || !w_abs || !ws || !loss_out || B_global < B) return SFM_ERR_ARG;
+  for (int m = 0; m < n_maps; ++m) {
+    if (!maps[m]) return SFM_ERR_ARG;
+    a.map[m] = maps[m];
+    a.grad[m] = d_maps ? d_maps[m] : nullptr;
+    a.w_smooth[m] = w_smooth[m];
+    a.w_abs[m] = w_abs[m];
+  }
+  a.b_global = (double)B_global;
+  a.gscale = gscale;
+  hipLaunchKernelGGL(smooth_loss_kernel, dim3((unsigned)a.blk0[n_maps]), dim3(kBlock), 0, (hipStream_t)stream, a, ws);
+  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(1), dim3(kSmoothReduceThreads), 0, (hipStream_t)stream, a, ws, loss_out);
+  return sfm_last_error();
+}

@@ -21,7 +21,9 @@ import torch
 
 from . import _lib
 from ._lib import call, ptr, stream_of
+from . import pyramid as P
 from . import utils as U
+from .pyramid import compute_smooth_loss, resize_bilinear  # noqa: F401  (the reference keeps them beside the loss)
 
 Tensor = torch.Tensor
 ALPHA = 0.15  # SfMLearner_uni.py:84
@@ -50,11 +52,12 @@ class LossEngine:
         flags = self.ws[-((S * N * B + 3) // 4 * 4):].view(torch.int32)[:S * N * B]
         return int((flags != 0).sum()), float(ovf.abs().max())
 
-    def forward_partials(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool = True) -> Tensor:
+    def forward_partials(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool = True,
+                         out: Optional[Tensor] = None) -> Tensor:
         """First half: both warps, the L1/SSIM stencil and the local partial sums.  ``n_elem_global`` =
         B_global*H*W*3 (the reduce_mean denominators are global under data parallelism)."""
         B, H, W, S, N = self.dims
-        partials = torch.empty(self.n_partials, dtype=torch.float64, device=self.device)
+        partials = out if out is not None else torch.empty(self.n_partials, dtype=torch.float64, device=self.device)
         st = stream_of(tgt)
         call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
         call("sfm_loss_forward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W, S,
@@ -107,67 +110,51 @@ def allreduce_partials(partials: Tensor, process_group=None) -> Tensor:
     return partials
 
 
-class _FusedPixelLoss(torch.autograd.Function):
-    """pixel_loss(depth [S,B,H,W], pose [B,N,6], trans [S,B,H,W,3N]); gradients are
-    computed in the forward (one fused pass) and scaled by the upstream scalar."""
+class _FusedTotalLoss(torch.autograd.Function):
+    """total_loss(pred_poses [B,N,6], pred_depth[0..S), pred_exp_logits[0..S), pred_disp[0..S) or nothing).
+
+    Everything between the network outputs and the scalar runs here as hand-written kernels, forward and
+    backward in one go: pyramid upsample (SfMLearner_uni.py:91,113), the fused warp + photometric pipeline
+    (:120-168), the smoothness / |t| regulariser (:94-101), and the adjoints back to the pyramid.  The
+    gradients are computed with the value and scaled by the upstream scalar in ``backward``."""
 
     @staticmethod
-    def forward(ctx, depth, pose, trans, tgt, src, K, process_group, global_b):
-        S, B, H, W = depth.shape
-        N = pose.shape[1]
+    def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, poses, *maps):
+        S = n_scales
+        pred_depth, pred_exp = list(maps[:S]), list(maps[S:2 * S])
+        pred_disp = list(maps[2 * S:3 * S])
+        B, H, W, _ = tgt.shape
+        N = poses.shape[1]
+        need = any(ctx.needs_input_grad[8:])
         with torch.cuda.device(tgt.device):
             eng = get_engine(B, H, W, S, N, tgt.device)
-            need = any(ctx.needs_input_grad[:3])
-            partials = eng.forward_partials(tgt, src, K, depth, pose, trans, global_b * H * W * 3, need)
+            depth = P.pyramid_upsample(pred_depth, H, W).view(S, B, H, W)
+            trans = P.pyramid_upsample(pred_exp, H, W)
+            n_elem = global_b * H * W * 3
+            # the pixel-loss partial sums and this rank's share of the smoothness term travel in ONE all-reduce
+            buf = torch.zeros(eng.n_partials + 1, dtype=torch.float64, device=tgt.device)
+            g_smooth = None
+            if smooth_weight > 0:
+                ws_, wa_ = P.smooth_weights(S, smooth_weight, explain_reg_weight)
+                sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need)
+                buf[-1] = sm
+            eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf[:-1])
             if global_b != B or process_group is not None:
-                partials = allreduce_partials(partials, process_group)
-            loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, pose, trans, partials,
-                                                          global_b * H * W * 3, 1.0, need)
-        if need:
-            ctx.save_for_backward(d_depth, d_pose, d_trans)
-        return loss
+                allreduce_partials(buf, process_group)
+            loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf[:-1], n_elem, 1.0, need)
+            total = loss + buf[-1].float()
+            if need:
+                g_depth = P.pyramid_upsample_grad(d_depth.view(S, B, H, W, 1), [(m.shape[1], m.shape[2]) for m in pred_depth])
+                # the regulariser's gradient of the translation maps is already in place: the adjoint adds to it
+                g_exp = P.pyramid_upsample_grad(d_trans, [(m.shape[1], m.shape[2]) for m in pred_exp],
+                                                accumulate_into=g_smooth[S:] if g_smooth is not None else None)
+                g_disp = g_smooth[:S] if g_smooth is not None else []
+                ctx.save_for_backward(d_pose, *g_depth, *g_exp, *g_disp)
+        return total
 
     @staticmethod
     def backward(ctx, g):
-        d_depth, d_pose, d_trans = ctx.saved_tensors
-        return d_depth * g, d_pose * g, d_trans * g, None, None, None, None, None
-
-
-def resize_bilinear(x_nhwc: Tensor, out_h: int, out_w: int) -> Tensor:
-    """``tf.image.resize_bilinear`` with TF-1 defaults (align_corners=False, no half-pixel
-    centres; SfMLearner_uni.py:91,113).  torch device glue, differentiable."""
-    _, in_h, in_w, _ = x_nhwc.shape
-    if (in_h, in_w) == (out_h, out_w):
-        return x_nhwc
-    dev, dt = x_nhwc.device, x_nhwc.dtype
-
-    def axis(in_n, out_n):
-        scale = torch.tensor(in_n / out_n, dtype=torch.float32, device=dev)
-        s = torch.arange(out_n, dtype=torch.float32, device=dev) * scale
-        lo = torch.floor(s).long()
-        hi = torch.clamp(lo + 1, max=in_n - 1)
-        return lo, hi, (s - lo.float()).to(dt)
-
-    ylo, yhi, yl = axis(in_h, out_h)
-    xlo, xhi, xl = axis(in_w, out_w)
-    top, bot = x_nhwc[:, ylo], x_nhwc[:, yhi]
-    xl_, yl_ = xl.reshape(1, 1, out_w, 1), yl.reshape(1, out_h, 1, 1)
-    top_i = top[:, :, xlo] + (top[:, :, xhi] - top[:, :, xlo]) * xl_
-    bot_i = bot[:, :, xlo] + (bot[:, :, xhi] - bot[:, :, xlo]) * xl_
-    return top_i + (bot_i - top_i) * yl_
-
-
-def compute_smooth_loss(pred: Tensor) -> Tensor:
-    """SfMLearner_uni.py:205-219 (torch device glue)."""
-    def gradient(p):
-        return p[:, :, 1:, :] - p[:, :, :-1, :], p[:, 1:, :, :] - p[:, :-1, :, :]
-    beta = 0.25
-    dx, dy = gradient(pred)
-    dx2, dxdy = gradient(dx)
-    dydx, dy2 = gradient(dy)
-    gx = dx.abs().mean() + dy.abs().mean()
-    hx = dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() + dy2.abs().mean()
-    return beta * gx + (1 - beta) * hx
+        return (None,) * 8 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 
 def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor,
@@ -193,6 +180,16 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
     S = len(pred_depth)
     if N < 2:
         raise IndexError("the min-reprojection term reads curr_errors[1] (SfMLearner_uni.py:168): need >= 2 sources")
+    if smooth_weight > 0 and (pred_disp is None or len(pred_disp) != S):
+        raise ValueError("smooth_weight > 0 needs pred_disp, one map per scale (SfMLearner_uni.py:96)")
+    if len(pred_exp_logits) != S:
+        raise ValueError("one pred_exp_logits map per scale")
+    if fused:
+        gb = global_batch_size if global_batch_size is not None else global_batch(B, process_group)
+        maps = list(pred_depth) + list(pred_exp_logits) + (list(pred_disp) if smooth_weight > 0 else [])
+        maps = [U._check(m, "pyramid map", 4) for m in maps]
+        return _FusedTotalLoss.apply(tgt, src, K, process_group, gb, float(smooth_weight), float(explain_reg_weight), S,
+                                     poses, *maps)
     smooth = tgt.new_zeros(())
     if smooth_weight > 0:
         for s in range(S):
@@ -201,12 +198,6 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
                 compute_smooth_loss(pred_exp_logits[s]) + pred_exp_logits[s].abs().mean())
     depth_full = [resize_bilinear(pred_depth[s], H, W).squeeze(3) for s in range(S)]
     trans_full = [resize_bilinear(pred_exp_logits[s], H, W) for s in range(S)]
-    if fused:
-        gb = global_batch_size if global_batch_size is not None else global_batch(B, process_group)
-        depth = torch.stack(depth_full, 0).contiguous()
-        trans = torch.stack(trans_full, 0).contiguous()
-        pixel = _FusedPixelLoss.apply(depth, poses, trans, tgt, src, K, process_group, gb)
-        return pixel + smooth
     pixel = tgt.new_zeros(())
     for s in range(S):
         errs = []

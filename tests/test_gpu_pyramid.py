@@ -1,0 +1,148 @@
+"""GPU parity of the pyramid kernels (csrc/pyramid.hip) against the CPU oracle:
+disp normalisation (SfMLearner_uni.py:40,47), tf.image.resize_bilinear (:91,113) and the smoothness /
+|t| regulariser (:94-101, 205-219), forward and backward, through the C ABI."""
+import pytest
+import torch
+
+import sfm_amd
+from sfm_amd import pyramid as P
+from oracle import ref_graph as R
+from helpers import TOL_GRAD, TOL_OUT, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).contiguous()
+
+
+@pytest.mark.parametrize("B,h,w,C,H,W", [
+    (2, 8, 12, 1, 16, 24),     # x2
+    (1, 16, 52, 6, 128, 416),  # x8, the coarsest KITTI scale, two sources' translations
+    (3, 5, 7, 3, 13, 17),      # ragged, non-integer ratio
+    (2, 16, 24, 6, 16, 24),    # identity
+    (1, 9, 11, 12, 37, 53),    # four sources
+])
+def test_resize_bilinear(dev, B, h, w, C, H, W):
+    x = _rand((B, h, w, C), 1)
+    go = _rand((B, H, W, C), 2)
+    xo = x.clone().requires_grad_(True)
+    yo = R.resize_bilinear_tf1(xo, H, W)
+    yo.backward(go)
+    xg = x.to(dev).requires_grad_(True)
+    yg = sfm_amd.resize_bilinear(xg, H, W)
+    yg.backward(go.to(dev))
+    assert torch.equal(yg.detach().cpu(), yo.detach()), "same fp32 op order: the upsample must be bit-exact"
+    assert rel_err(xg.grad, xo.grad) <= TOL_OUT
+
+
+def test_pyramid_upsample_stacks_all_scales(dev):
+    B, H, W, C = 2, 32, 64, 6
+    maps = [_rand((B, H >> s, W >> s, C), 10 + s) for s in range(4)]
+    out = P.pyramid_upsample([m.to(dev) for m in maps], H, W)
+    assert out.shape == (4, B, H, W, C)
+    for s in range(4):
+        assert torch.equal(out[s].cpu(), R.resize_bilinear_tf1(maps[s], H, W))
+    go = _rand((4, B, H, W, C), 20)
+    gin = P.pyramid_upsample_grad(go.to(dev), [(m.shape[1], m.shape[2]) for m in maps])
+    for s in range(4):
+        xo = maps[s].clone().requires_grad_(True)
+        R.resize_bilinear_tf1(xo, H, W).backward(go[s])
+        assert rel_err(gin[s], xo.grad) <= TOL_OUT
+
+
+def test_resize_rejects_downsampling_and_cpu(dev):
+    with pytest.raises(ValueError):
+        sfm_amd.resize_bilinear(torch.zeros(1, 8, 8, 1, device=dev), 4, 4)
+    with pytest.raises(TypeError):
+        sfm_amd.resize_bilinear(torch.zeros(1, 4, 4, 1), 8, 8)
+
+
+@pytest.mark.parametrize("B,h,w,C", [(2, 16, 24, 1), (1, 3, 3, 6), (3, 13, 17, 6), (1, 128, 416, 1), (2, 5, 4, 12)])
+def test_compute_smooth_loss(dev, B, h, w, C):
+    x = _rand((B, h, w, C), 3)
+    xo = x.clone().requires_grad_(True)
+    lo = R.compute_smooth_loss(xo)
+    lo.backward()
+    xg = x.to(dev).requires_grad_(True)
+    lg = sfm_amd.compute_smooth_loss(xg)
+    (2.0 * lg).backward()
+    assert rel_err(lg, lo) <= TOL_OUT
+    assert rel_err(xg.grad, 2.0 * xo.grad) <= TOL_OUT
+
+
+def test_smooth_regulariser_all_maps_one_launch(dev):
+    """smooth_loss of the scale loop (SfMLearner_uni.py:94-101) over S disparity and S translation maps,
+    data-parallel denominators included (global batch 2x the local one)."""
+    B, H, W, S, N = 2, 32, 64, 4, 2
+    disp = [_rand((B, H >> s, W >> s, 1), 30 + s).abs() + 0.1 for s in range(S)]
+    exp = [_rand((B, H >> s, W >> s, 3 * N), 40 + s, 0.01) for s in range(S)]
+    do = [d.clone().requires_grad_(True) for d in disp]
+    eo = [e.clone().requires_grad_(True) for e in exp]
+    sw, er = 0.01, 0.01
+    lo = sum(sw / 2 ** s * R.compute_smooth_loss(do[s]) + er / 2 ** s * (R.compute_smooth_loss(eo[s]) + eo[s].abs().mean())
+             for s in range(S))
+    lo.backward()
+    ws, wa = P.smooth_weights(S, sw, er)
+    for gb in (B, 2 * B):
+        lg, grads = P.smooth_terms([t.to(dev) for t in disp + exp], ws, wa, gb, True)
+        k = B / gb
+        assert rel_err(lg, k * lo) <= TOL_OUT
+        for s in range(S):
+            assert rel_err(grads[s], k * do[s].grad) <= TOL_OUT
+            assert rel_err(grads[S + s], k * eo[s].grad) <= TOL_OUT
+
+
+def test_smooth_sign_at_exact_zero(dev):
+    """abs'(0) = 0 in TF and torch alike: a constant map has zero loss and zero gradient."""
+    x = torch.full((1, 6, 7, 3), 0.25, device=dev).requires_grad_(True)
+    l = sfm_amd.compute_smooth_loss(x)
+    l.backward()
+    assert float(l.detach()) == 0.0 and float(x.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,sizes", [(2, [(16, 24), (8, 12)]), (3, [(128, 416), (64, 208), (32, 104), (16, 52)]), (1, [(5, 7)])])
+def test_normalize_disp(dev, B, sizes):
+    raw = [10.0 * torch.sigmoid(_rand((B, h, w, 1), 50 + k)) + 0.01 for k, (h, w) in enumerate(sizes)]
+    gu = [_rand(r.shape, 60 + k) for k, r in enumerate(raw)]
+    gd = [_rand(r.shape, 70 + k) for k, r in enumerate(raw)]
+    ro = [r.clone().requires_grad_(True) for r in raw]
+    dno, dpo = R.normalize_disp(ro)
+    sum((a * g).sum() for a, g in zip(dno, gu)).add(sum((a * g).sum() for a, g in zip(dpo, gd))).backward()
+    rg = [r.to(dev).requires_grad_(True) for r in raw]
+    dng, dpg = sfm_amd.normalize_disp(rg)
+    sum((a * g.to(dev)).sum() for a, g in zip(dng, gu)).add(sum((a * g.to(dev)).sum() for a, g in zip(dpg, gd))).backward()
+    for k in range(len(sizes)):
+        assert rel_err(dng[k], dno[k]) <= TOL_OUT
+        assert rel_err(dpg[k], dpo[k]) <= TOL_OUT
+        assert rel_err(rg[k].grad, ro[k].grad) <= TOL_GRAD
+
+
+def test_total_loss_from_raw_network_outputs(dev):
+    """disp -> normalise -> depth -> pyramid upsample -> warps + photometric loss + smoothness, end to end
+    from the raw disparity pyramid (SfMLearner_uni.py:40-176), gradients back to the raw disparities."""
+    from sfm_amd import synth
+    B, H, W, S, N = 2, 32, 64, 3, 2
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=77, full_res=False)
+    raw = [10.0 * torch.sigmoid(_rand(d.shape, 80 + k)) + 0.01 for k, d in enumerate(inp["disp"])]
+
+    ro = [r.clone().requires_grad_(True) for r in raw]
+    to = [t.clone().requires_grad_(True) for t in inp["trans"]]
+    po = inp["pose"].clone().requires_grad_(True)
+    dno, dpo = R.normalize_disp(ro)
+    lo = R.multi_scale_loss(inp["tgt"], inp["src"], inp["K"], dpo, po, to, pred_disp=dno, smooth_weight=0.01)
+    lo.backward()
+
+    g = synth.to_device(inp, dev)
+    rg = [r.to(dev).requires_grad_(True) for r in raw]
+    tg = [t.requires_grad_(True) for t in g["trans"]]
+    pg = g["pose"].requires_grad_(True)
+    dng, dpg = sfm_amd.normalize_disp(rg)
+    lg = sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], dpg, pg, tg, pred_disp=dng, smooth_weight=0.01)
+    lg.backward()
+    assert rel_err(lg, lo) <= TOL_OUT
+    assert rel_err(pg.grad, po.grad) <= TOL_GRAD
+    for s in range(S):
+        assert rel_err(rg[s].grad, ro[s].grad) <= TOL_GRAD, f"raw disparity scale {s}"
+        assert rel_err(tg[s].grad, to[s].grad) <= TOL_GRAD, f"translations scale {s}"
