@@ -126,6 +126,38 @@ def aspp_leg(dev, reps: int = 5) -> dict:
             "ms": ms, "flops": flops, "dtype": "f32"}
 
 
+def total_loss_leg(dev, reps: int = 50) -> dict:
+    """SURVEY.md 8(f) rows 1-2 widened path: total_loss of SfMLearner_uni.py:40-176 from the raw network outputs
+    (disparity / translation pyramids at H/2^s, poses) through the Python mirror - disp normalisation, pyramid
+    upsample, the fused step above, smoothness regulariser and every adjoint - host overhead included."""
+    import sfm_amd
+    from sfm_amd import synth
+    inp = synth.to_device(synth.make_inputs(B, H, W, S=S, N=N, seed=synth.SEED, full_res=False), dev)
+    raw = [(d * 3.0).requires_grad_(True) for d in inp["disp"]]
+    trans = [t.requires_grad_(True) for t in inp["trans"]]
+    pose = inp["pose"].requires_grad_(True)
+
+    def step():
+        for t in raw + trans + [pose]:
+            t.grad = None
+        dn, dp = sfm_amd.normalize_disp(raw)
+        loss = sfm_amd.multi_scale_loss(inp["tgt"], inp["src"], inp["K"], dp, pose, trans, pred_disp=dn, smooth_weight=0.01)
+        loss.backward()
+        return loss
+
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"workload": f"total_loss fwd+bwd from raw pyramids (scale s at {H}>>s x {W}>>s), B={B}, smooth_weight=0.01, "
+                        f"through sfm_amd.multi_scale_loss (autograd, host overhead included)",
+            "ms_per_call": ms, "Gpix_per_s": B * H * W * S * N * 2 / (ms * 1e-3) / 1e9, "loss": float(loss.detach())}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +258,8 @@ def main() -> None:
         if world == 1 and not args.no_aspp:
             line["aspp"] = aspp_leg(dev)
             line["config"]["config5_step_ms"] = ms_step + line["aspp"]["ms"]  # ASPP convs + warp loss, fwd + bwd
+        if world == 1 and not args.no_aspp:
+            line["end_to_end"] = total_loss_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth.SEED)
         print(json.dumps(line), flush=True)

@@ -156,6 +156,40 @@ __device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_n) {
   return o;
 }
 
+// C consecutive floats as the widest chunks whose alignment the NHWC layout guarantees
+template <int C>
+__device__ __forceinline__ void ld_vec(const float* __restrict__ p, float (&v)[C]) {
+  if constexpr (C % 3 == 0) {
+#pragma unroll
+    for (int j = 0; j < C / 3; ++j) { const f3 t = ld3(p + 3 * j); v[3 * j] = t.x; v[3 * j + 1] = t.y; v[3 * j + 2] = t.z; }
+  } else if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < C / 4; ++j) { const float4 t = *reinterpret_cast<const float4*>(p + 4 * j); v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
+  } else if constexpr (C % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < C / 2; ++j) { const float2 t = *reinterpret_cast<const float2*>(p + 2 * j); v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < C; ++j) v[j] = p[j];
+  }
+}
+template <int C>
+__device__ __forceinline__ void st_vec(float* __restrict__ p, const float (&v)[C]) {
+  if constexpr (C % 3 == 0) {
+#pragma unroll
+    for (int j = 0; j < C / 3; ++j) st3(p + 3 * j, v[3 * j], v[3 * j + 1], v[3 * j + 2]);
+  } else if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < C / 4; ++j) *reinterpret_cast<float4*>(p + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+  } else if constexpr (C % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < C / 2; ++j) *reinterpret_cast<float2*>(p + 2 * j) = make_float2(v[2 * j], v[2 * j + 1]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < C; ++j) p[j] = v[j];
+  }
+}
+
 struct PyrArgs {
   const float* in[kMaxMaps];
   float* gin[kMaxMaps];
@@ -176,16 +210,19 @@ __device__ __forceinline__ int scale_of_block(const PyrArgs& a, int blk) {
 template <int C>
 __global__ __launch_bounds__(kBlock) void pyramid_upsample_fwd_kernel(PyrArgs a, float* __restrict__ out) {
   const int s = scale_of_block(a, blockIdx.x);
-  const long k = (long)(blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
-  const long npx = (long)a.B * a.H * a.W;
+  // 32-bit index arithmetic (B*H*W < 2^31 is checked on the host): 64-bit divisions cost more than the lerp
+  const unsigned k = (blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
+  const unsigned npx = (unsigned)a.B * a.H * a.W;
   if (k >= npx) return;
-  const int X = (int)(k % a.W), Y = (int)((k / a.W) % a.H), b = (int)(k / ((long)a.W * a.H));
+  const unsigned row_ = k / (unsigned)a.W;
+  const int X = (int)(k - row_ * a.W), b = (int)(row_ / (unsigned)a.H), Y = (int)(row_ - (unsigned)b * a.H);
   const int h = a.h[s], w = a.w[s];
   const float* __restrict__ in = a.in[s] + (size_t)b * h * w * C;
   float* __restrict__ o = out + ((size_t)s * npx + k) * C;
+  float vo[C];
   if (h == a.H && w == a.W) {  // tf.image.resize_bilinear at the same size is the identity
-#pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = in[((size_t)Y * w + X) * C + c];
+    ld_vec<C>(in + ((size_t)Y * w + X) * C, vo);
+    st_vec<C>(o, vo);
     return;
   }
   const Lerp ly = lerp_of(Y, a.sy[s], h), lx = lerp_of(X, a.sx[s], w);
@@ -193,12 +230,15 @@ __global__ __launch_bounds__(kBlock) void pyramid_upsample_fwd_kernel(PyrArgs a,
   const float* tr = in + ((size_t)ly.lo * w + lx.hi) * C;
   const float* bl = in + ((size_t)ly.hi * w + lx.lo) * C;
   const float* br = in + ((size_t)ly.hi * w + lx.hi) * C;
+  float vtl[C], vtr[C], vbl[C], vbr[C];
+  ld_vec<C>(tl, vtl); ld_vec<C>(tr, vtr); ld_vec<C>(bl, vbl); ld_vec<C>(br, vbr);
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    const float top = tl[c] + (tr[c] - tl[c]) * lx.l;
-    const float bot = bl[c] + (br[c] - bl[c]) * lx.l;
-    o[c] = top + (bot - top) * ly.l;
+    const float top = vtl[c] + (vtr[c] - vtl[c]) * lx.l;
+    const float bot = vbl[c] + (vbr[c] - vbl[c]) * lx.l;
+    vo[c] = top + (bot - top) * ly.l;
   }
+  st_vec<C>(o, vo);
 }
 
 // Adjoint (ResizeBilinearGrad) as two separable GATHER passes - the upsample is R_y (x) R_x, so its adjoint
@@ -213,16 +253,23 @@ __global__ __launch_bounds__(kBlock) void pyramid_upsample_bwd_x_kernel(PyrArgs 
                                                                         float* __restrict__ tmp) {
   const int s = scale_of_block(a, blockIdx.x);
   const int h = a.h[s], w = a.w[s];
-  const long k = (long)(blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
-  if (k >= (long)a.B * a.H * w) return;
-  const int x = (int)(k % w), Y = (int)((k / w) % a.H), b = (int)(k / ((long)w * a.H));
-  const long npx = (long)a.B * a.H * a.W;
+  const unsigned k = (blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
+  if (k >= (unsigned)a.B * a.H * w) return;
+  const unsigned row_ = k / (unsigned)w;
+  const int x = (int)(k - row_ * w), b = (int)(row_ / (unsigned)a.H), Y = (int)(row_ - (unsigned)b * a.H);
+  const size_t npx = (size_t)a.B * a.H * a.W;
   const float* __restrict__ g = gout + ((size_t)s * npx + ((size_t)b * a.H + Y) * a.W) * C;
   float acc[C];
   if (h == a.H && w == a.W) {  // identity scale: straight to the output (pass 2 skips it)
     float* __restrict__ o = a.gin[s] + (size_t)k * C;
+    ld_vec<C>(g + (size_t)x * C, acc);
+    if (a.accumulate) {
+      float prev[C];
+      ld_vec<C>(o, prev);
 #pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = a.accumulate ? o[c] + g[(size_t)x * C + c] : g[(size_t)x * C + c];
+      for (int c = 0; c < C; ++c) acc[c] += prev[c];
+    }
+    st_vec<C>(o, acc);
     return;
   }
 #pragma unroll
@@ -233,13 +280,12 @@ __global__ __launch_bounds__(kBlock) void pyramid_upsample_bwd_x_kernel(PyrArgs 
     const Lerp lx = lerp_of(X, a.sx[s], w);
     if (lx.lo != x && lx.hi != x) continue;
     const float wx = (lx.lo == x ? 1.0f - lx.l : 0.0f) + (lx.hi == x ? lx.l : 0.0f);
-    const float* gp = g + (size_t)X * C;
+    float gv[C];
+    ld_vec<C>(g + (size_t)X * C, gv);
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] += gp[c] * wx;
+    for (int c = 0; c < C; ++c) acc[c] += gv[c] * wx;
   }
-  float* __restrict__ o = tmp + (a.tmp0[s] + (size_t)k) * C;
-#pragma unroll
-  for (int c = 0; c < C; ++c) o[c] = acc[c];
+  st_vec<C>(tmp + (a.tmp0[s] + (size_t)k) * C, acc);
 }
 
 template <int C>
@@ -247,9 +293,10 @@ __global__ __launch_bounds__(kBlock) void pyramid_upsample_bwd_y_kernel(PyrArgs 
   const int s = scale_of_block(a, blockIdx.x);
   const int h = a.h[s], w = a.w[s];
   if (h == a.H && w == a.W) return;
-  const long k = (long)(blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
-  if (k >= (long)a.B * h * w) return;
-  const int x = (int)(k % w), y = (int)((k / w) % h), b = (int)(k / ((long)w * h));
+  const unsigned k = (blockIdx.x - a.blk0[s]) * kBlock + threadIdx.x;
+  if (k >= (unsigned)a.B * h * w) return;
+  const unsigned row_ = k / (unsigned)w;
+  const int x = (int)(k - row_ * w), b = (int)(row_ / (unsigned)h), y = (int)(row_ - (unsigned)b * h);
   const float* __restrict__ t = tmp + (a.tmp0[s] + (size_t)b * a.H * w + x) * C;
   float acc[C];
 #pragma unroll
@@ -260,13 +307,19 @@ __global__ __launch_bounds__(kBlock) void pyramid_upsample_bwd_y_kernel(PyrArgs 
     const Lerp ly = lerp_of(Y, a.sy[s], h);
     if (ly.lo != y && ly.hi != y) continue;
     const float wy = (ly.lo == y ? 1.0f - ly.l : 0.0f) + (ly.hi == y ? ly.l : 0.0f);
-    const float* tp = t + (size_t)Y * w * C;
+    float tv[C];
+    ld_vec<C>(t + (size_t)Y * w * C, tv);
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] += tp[c] * wy;
+    for (int c = 0; c < C; ++c) acc[c] += tv[c] * wy;
   }
   float* __restrict__ o = a.gin[s] + (size_t)k * C;
+  if (a.accumulate) {
+    float prev[C];
+    ld_vec<C>(o, prev);
 #pragma unroll
-  for (int c = 0; c < C; ++c) o[c] = a.accumulate ? o[c] + acc[c] : acc[c];
+    for (int c = 0; c < C; ++c) acc[c] += prev[c];
+  }
+  st_vec<C>(o, acc);
 }
 
 // ------------------------------------------------------------------ smoothness + |t| regulariser
@@ -321,14 +374,15 @@ __global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, float
     const int xi = (int)x, yi = (int)y, wi = (int)w, hi = (int)h;
     // the 13 samples every difference below is made of: row y at x-2..x+2, column x at y-2..y+2 and the
     // four diagonal neighbours; clamped addresses (a clamped sample is never used: see the range tests)
-    const float* __restrict__ p = map + (size_t)(k - (y * w + x) * C - c) + c;  // channel c of the batch item
-    auto P = [&](int dy, int dx) {
-      const int yy = min(max(yi + dy, 0), hi - 1), xx = min(max(xi + dx, 0), wi - 1);
-      return p[((size_t)yy * w + xx) * C];
-    };
-    const float p00 = P(0, 0), pm2 = P(0, -2), pm1 = P(0, -1), pp1 = P(0, 1), pp2 = P(0, 2);
-    const float qm2 = P(-2, 0), qm1 = P(-1, 0), qp1 = P(1, 0), qp2 = P(2, 0);
-    const float dmm = P(-1, -1), dmp = P(-1, 1), dpm = P(1, -1), dpp = P(1, 1);
+    const float* __restrict__ p = map + k;  // this element; neighbours by (clamped) signed offsets
+    const int sx = (int)C, sy = (int)(w * C);
+    const int oxm2 = (max(xi - 2, 0) - xi) * sx, oxm1 = (max(xi - 1, 0) - xi) * sx;
+    const int oxp1 = (min(xi + 1, wi - 1) - xi) * sx, oxp2 = (min(xi + 2, wi - 1) - xi) * sx;
+    const int oym2 = (max(yi - 2, 0) - yi) * sy, oym1 = (max(yi - 1, 0) - yi) * sy;
+    const int oyp1 = (min(yi + 1, hi - 1) - yi) * sy, oyp2 = (min(yi + 2, hi - 1) - yi) * sy;
+    const float p00 = p[0], pm2 = p[oxm2], pm1 = p[oxm1], pp1 = p[oxp1], pp2 = p[oxp2];
+    const float qm2 = p[oym2], qm1 = p[oym1], qp1 = p[oyp1], qp2 = p[oyp2];
+    const float dmm = p[oym1 + oxm1], dmp = p[oym1 + oxp1], dpm = p[oyp1 + oxm1], dpp = p[oyp1 + oxp1];
     // first differences, named by their anchor relative to (y, x): dx_ab = DX(y + a, x + b) = P(.., +1) - P(..)
     const float dx_0m2 = pm1 - pm2, dx_0m1 = p00 - pm1, dx_00 = pp1 - p00, dx_0p1 = pp2 - pp1;
     const float dx_p1m1 = qp1 - dpm, dx_p10 = dpp - qp1, dx_m1m1 = qm1 - dmm, dx_m10 = dmp - qm1;
@@ -397,7 +451,7 @@ static inline int blocks_for(long n) { return (int)((n + kBlock - 1) / kBlock); 
 // mode: grid over 0 = output pixels [B,H,W], 1 = the backward intermediate [B,H,w_s], 2 = input pixels [B,h_s,w_s]
 static int fill_pyr(PyrArgs& a, const int* h, const int* w, int S, int B, int C, int H, int W, int mode) {
   if (!h || !w || S < 1 || S > kMaxMaps || B < 1 || H < 1 || W < 1 || C < 1 || C > kMaxC) return SFM_ERR_ARG;
-  if (!sfm_fits(H, W, C)) return SFM_ERR_TOO_LARGE;
+  if (!sfm_fits(H, W, C) || (long)B * H * W >= 2147483647L) return SFM_ERR_TOO_LARGE;
   a.S = S; a.B = B; a.C = C; a.H = H; a.W = W;
   long blk = 0;
   for (int s = 0; s < S; ++s) {
