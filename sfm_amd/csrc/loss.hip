@@ -63,11 +63,12 @@ __device__ __forceinline__ int4 scan_rect(int tx, int ty, int4 sft) {
   return make_int4(xl, xl + STW + 2 * sft.z, yl, yl + STH + 2 * sft.w);
 }
 
-// One thread per (image, tile): mid-range and half-range of the displacement (x - u, y - v) over a
-// 3x3 grid of sample pixels of the tile -> shift and reach of the tile's scan window.  A pixel at u
-// with displacement in [lo, hi] has corners floor(u + dx) + {0, 1}: reach = half-range + 1.5 covers the
-// sampled spread; the additive margin (kReachAdd) covers the variation between samples.  Any table is correct; a good one
-// keeps the overflow rare and the scan small.
+// Sixteen lanes per (image, tile), nine of them active: mid-range and half-range of the displacement (x - u, y - v)
+// over a 3x3 grid of sample pixels of the tile -> shift and reach of the tile's scan window.  One sample per lane, so
+// the kernel is one load round trip deep (it ran nine dependent ones when a thread walked the samples); the 16-lane
+// min / max reduction is a shuffle butterfly.  A pixel at u with displacement in [lo, hi] has corners
+// floor(u + dx) + {0, 1}: reach = half-range + 1.5 covers the sampled spread; the additive margin (kReachAdd) covers
+// the variation between samples.  Any table is correct; a good one keeps the overflow rare and the scan small.
 __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __restrict__ depth,
                                                                  const float* __restrict__ trans,
                                                                  const float* __restrict__ params, LossDims d,
@@ -75,31 +76,38 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
                                                                  int4* __restrict__ shift, int radd, int rmin, int rmax) {
   const int ntile = tiles_x * tiles_y;
   const long total = (long)d.S * d.N * d.B * ntile;
-  const long k = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= total) return;
-  const int tile = (int)(k % ntile);
-  const int img = (int)(k / ntile);  // (s*N + i)*B + b
+  const long k = ((long)blockIdx.x * kBlock + threadIdx.x) >> 4;
+  const int j = threadIdx.x & 15;  // sample (jy, jx) = (j / 3, j % 3) for j < 9
+  const bool tile_ok = k < total;
+  const long kc = tile_ok ? k : total - 1;  // idle groups redo the last tile: every lane takes part in the shuffles
+  const int tile = (int)(kc % ntile);
+  const int img = (int)(kc / ntile);  // (s*N + i)*B + b
   const int b = img % d.B, si = img / d.B, i = si % d.N, s = si / d.N;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int HW = d.H * d.W, C3 = 3 * d.N;
-  const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-  const size_t sb = ((size_t)s * d.B + b) * HW;
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
   const int xa = tx * STW, ya = ty * STH;
   const int xb = min(xa + STW, d.W) - 1, yb = min(ya + STH, d.H) - 1;
   float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f;
-  for (int jy = 0; jy < 3; ++jy)
-    for (int jx = 0; jx < 3; ++jx) {
-      const int u = xa + ((xb - xa) * jx) / 2, v = ya + ((yb - ya) * jy) / 2;
-      const int p = v * d.W + u;
-      const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
-      const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), depth[sb + p], true, t.x,
-                              t.y, t.z);
-      // displacement of the clipped landing point (what the corners are clipped to)
-      const float ddx = fminf(fmaxf(g.x, 0.0f), xmax) - (float)u, ddy = fminf(fmaxf(g.y, 0.0f), ymax) - (float)v;
-      lo_x = fminf(lo_x, ddx); hi_x = fmaxf(hi_x, ddx);
-      lo_y = fminf(lo_y, ddy); hi_y = fmaxf(hi_y, ddy);
-    }
+  if (j < 9) {
+    const int jy = j / 3, jx = j - 3 * jy;
+    const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
+    const size_t sb = ((size_t)s * d.B + b) * HW;
+    const int u = xa + ((xb - xa) * jx) / 2, v = ya + ((yb - ya) * jy) / 2;
+    const int p = v * d.W + u;
+    const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
+    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), depth[sb + p], true, t.x, t.y,
+                            t.z);
+    // displacement of the clipped landing point (what the corners are clipped to); NaNs drop out of fmin / fmax
+    lo_x = hi_x = fminf(fmaxf(g.x, 0.0f), xmax) - (float)u;
+    lo_y = hi_y = fminf(fmaxf(g.y, 0.0f), ymax) - (float)v;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    lo_x = fminf(lo_x, __shfl_xor(lo_x, o, 16)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o, 16));
+    lo_y = fminf(lo_y, __shfl_xor(lo_y, o, 16)); hi_y = fmaxf(hi_y, __shfl_xor(hi_y, o, 16));
+  }
+  if (j != 0 || !tile_ok) return;
   const float mx = 0.5f * (lo_x + hi_x), my = 0.5f * (lo_y + hi_y);
   const float hx = 0.5f * (hi_x - lo_x), hy = 0.5f * (hi_y - lo_y);
   int4 o;
@@ -612,7 +620,7 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   { StageTimer t(ST_SHIFT, stream);
   const long n = (long)w.n_img * w.stiles_x * w.stiles_y;
-  hipLaunchKernelGGL(loss_tile_shift_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, depth,
+  hipLaunchKernelGGL(loss_tile_shift_kernel, dim3((unsigned)((n * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, depth,
                      trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift,
                      kReachAdd, kReachMin, kReachMax); }
   { StageTimer t(ST_WARP_FWD, stream);

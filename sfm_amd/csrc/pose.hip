@@ -162,7 +162,13 @@ __global__ __launch_bounds__(kBlock) void pose_grad_kernel(const float* __restri
   double rx = fmin(fmax((double)pv[3], -(double)kPiF), (double)kPiF);
   double ry = fmin(fmax((double)pv[4], -(double)kPiF), (double)kPiF);
   double rz = fmin(fmax((double)pv[5], -(double)kPiF), (double)kPiF);
-  double sx = sin(rx), cx = cos(rx), sy = sin(ry), cy = cos(ry), sz = sin(rz), cz = cos(rz);
+  // fp32 sin / cos (1 ulp) widened: the forward's own values are fp32, and fp64 sincos is ~4 us of serial
+  // single-thread latency at the end of every step
+  float sxf, cxf, syf, cyf, szf, czf;
+  sincosf((float)rx, &sxf, &cxf);
+  sincosf((float)ry, &syf, &cyf);
+  sincosf((float)rz, &szf, &czf);
+  const double sx = sxf, cx = cxf, sy = syf, cy = cyf, sz = szf, cz = czf;
   double X[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
   double Y[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy};
   double Z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
