@@ -2,11 +2,12 @@
 
 ``multi_scale_loss`` mirrors the reference's loop given the same tensors:
 
-    fused=True   one pass of the fused HIP pipeline (sfm_loss_forward / sfm_loss_backward,
-                 csrc/loss.hip): geometry evaluated once per (pixel, source), both warps,
-                 L1 + SSIM, masks, min-reprojection and every gradient in 8 launches (7 kernels + pose set-up).
+    fused=True   one autograd.Function from the network outputs to the scalar: pyramid upsample and
+                 smoothness regulariser (csrc/pyramid.hip) around one pass of the fused HIP pipeline
+                 (sfm_loss_forward / sfm_loss_backward, csrc/loss.hip): geometry evaluated once per
+                 (pixel, source), both warps, L1 + SSIM, masks, min-reprojection and every gradient.
     fused=False  the reference's op decomposition, each op a stand-alone HIP operator of
-                 ``sfm_amd.utils`` glued by torch device ops and torch autograd.
+                 ``sfm_amd.utils`` / ``sfm_amd.pyramid`` chained by torch autograd.
 
 Data parallelism (SURVEY.md section 8e): the batch of snippets is sharded over ranks;
 the only exchange is one all-reduce of S*(3N+1) fp64 partial sums between the two
