@@ -126,6 +126,20 @@ int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, int N, void* 
 int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
                      const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
                      int need_grad, double* partials, void* stream);
+/* The forward in two halves, so that a data-parallel step can hide its collectives (no counterpart in the
+ * single-device reference; same arithmetic as sfm_loss_forward): _splat = both warps + the splat-side stencil and
+ * its 3N sums per scale (written into the [S][3N+1] partials layout, the min-reprojection slots untouched);
+ * _gather = the gather-side stencil and the min-reprojection sums e_sums[S] (fp64).  Order per step:
+ * _splat, [all-reduce partials] || _gather, [all-reduce e_sums] || sfm_loss_backward (its loss_out is then
+ * meaningless), sfm_loss_value(partials, e_sums) for the loss. */
+int sfm_loss_forward_splat(const float* tgt, const float* src, const float* depth, const float* trans,
+                           const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
+                           int need_grad, double* partials, void* stream);
+int sfm_loss_forward_gather(const float* tgt, const float* src, const float* depth, const float* trans,
+                            const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
+                            int need_grad, double* partials, double* e_sums, void* stream);
+int sfm_loss_value(const double* partials, const double* e_sums, int S, int N, long long n_elem_global, float* loss_out,
+                   void* stream);
 int sfm_loss_backward(const float* tgt, const float* src, const float* depth, const float* trans,
                       const float* params, float* ws, int B, int H, int W, int S, int N,
                       long long n_elem_global, float gloss, int need_grad, const double* partials,

@@ -307,10 +307,13 @@ __global__ __launch_bounds__(kBlock) void loss_ovf_clear_kernel(float* __restric
 // ------------------------------------------------------------------ reduce
 // per-wave partial sums of the stencil kernel -> partials fp64 [S][3N+1], fixed summation order
 // (deterministic).  grid (S, 3N+1): block (s, t) owns one term.
+// t0: first term of the launch (grid.y terms from there); e_out (may be null): where the min-reprojection sum of a
+// scale goes instead of partials[s][3N] (the overlapped data-parallel step reduces the two sides separately).
 __global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __restrict__ wavep, LossDims d, StencilPlan p,
-                                                             double* __restrict__ partials) {
+                                                             double* __restrict__ partials, int t0,
+                                                             double* __restrict__ e_out) {
   __shared__ double red[kBlock];
-  const int s = blockIdx.x, t = blockIdx.y;
+  const int s = blockIdx.x, t = t0 + blockIdx.y;
   const int nterm = 3 * d.N + 1;
   const long per = (long)d.B * p.per_img;  // waves per (scale, source) image set
   long first;
@@ -331,7 +334,10 @@ __global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __rest
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partials[(size_t)s * nterm + t] = red[0];
+  if (threadIdx.x == 0) {
+    if (t == 3 * d.N && e_out) e_out[s] = red[0];
+    else partials[(size_t)s * nterm + t] = red[0];
+  }
 }
 
 // ------------------------------------------------------------------ finalize
@@ -345,7 +351,8 @@ __device__ __forceinline__ float loss_kv(const double* __restrict__ partials, in
   return (float)((1.0 - (double)kAlpha) * (M / n_elem) * (-0.5) * pass / n_elem);
 }
 
-__device__ __forceinline__ float loss_value(const double* __restrict__ partials, int S, int N, double n_elem) {
+__device__ __forceinline__ float loss_value(const double* __restrict__ partials, int S, int N, double n_elem,
+                                            const double* __restrict__ e_sums = nullptr) {
   const int nterm = 3 * N + 1;
   const double a = (double)kAlpha;
   double loss = 0.0;
@@ -357,15 +364,15 @@ __device__ __forceinline__ float loss_value(const double* __restrict__ partials,
       const float sc = fminf(fmaxf(h, 0.0f), 1.0f);
       loss += a * (A / n_elem) + (1.0 - a) * (double)sc * (M / n_elem);
     }
-    loss += 2.0 * partials[s * nterm + 3 * N] / n_elem;
+    loss += 2.0 * (e_sums ? e_sums[s] : partials[s * nterm + 3 * N]) / n_elem;
   }
   return (float)loss;
 }
 
 // forward-only steps: just the loss (with gradients, the backward warp kernel does this itself)
 __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S, int N, double n_elem,
-                                     float* __restrict__ loss_out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *loss_out = loss_value(partials, S, N, n_elem);
+                                     float* __restrict__ loss_out, const double* __restrict__ e_sums) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *loss_out = loss_value(partials, S, N, n_elem, e_sums);
 }
 
 // ------------------------------------------------------------------ fused warp backward
@@ -607,9 +614,11 @@ extern "C" int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, in
   return e == hipSuccess ? SFM_OK : (int)e;
 }
 
-extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
-                                const float* params, float* ws, int B, int H, int W, int S, int N,
-                                long long n_elem_global, int need_grad, double* partials, void* stream_) {
+// phases of the forward: 1 = tile_shift + both warps + splat-side stencil + its 3N sums per scale,
+// 2 = gather-side stencil + the min-reprojection sum per scale, 3 = everything in the plain order
+static int loss_forward_phases(int phases, const float* tgt, const float* src, const float* depth, const float* trans,
+                               const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
+                               int need_grad, double* partials, double* e_out, void* stream_) {
   LossDims d{B, H, W, S, N};
   if (!tgt || !src || !depth || !trans || !params || !ws || !partials || n_elem_global <= 0 || !dims_ok(d))
     return SFM_ERR_ARG;
@@ -618,24 +627,79 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
   const LossWs& w = l.w;
   int4* shift = reinterpret_cast<int4*>(ws + w.shift);
   int* flags = reinterpret_cast<int*>(ws + w.flags);
-  { StageTimer t(ST_SHIFT, stream);
-  const long n = (long)w.n_img * w.stiles_x * w.stiles_y;
-  hipLaunchKernelGGL(loss_tile_shift_kernel, dim3((unsigned)((n * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, depth,
-                     trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift,
-                     kReachAdd, kReachMin, kReachMax); }
-  { StageTimer t(ST_WARP_FWD, stream);
-  hipLaunchKernelGGL(loss_splat_tile_kernel, dim3((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img)), dim3(kSplatThreads), 0,
-                     stream, tgt, src, depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
-                     flags); }
-  int rc = sfm_last_error();
-  if (rc) return rc;
-  { StageTimer t(ST_STENCIL, stream);
+  int rc;
+  if (phases & 1) {
+    { StageTimer t(ST_SHIFT, stream);
+    const long n = (long)w.n_img * w.stiles_x * w.stiles_y;
+    hipLaunchKernelGGL(loss_tile_shift_kernel, dim3((unsigned)((n * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, depth,
+                       trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift,
+                       kReachAdd, kReachMin, kReachMax); }
+    { StageTimer t(ST_WARP_FWD, stream);
+    hipLaunchKernelGGL(loss_splat_tile_kernel, dim3((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img)), dim3(kSplatThreads), 0,
+                       stream, tgt, src, depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
+                       flags); }
+    rc = sfm_last_error();
+    if (rc) return rc;
+  }
   StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, ws + w.Hb, ws + w.dG, ws + w.wavep, d, l.sp,
                 (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global)};
-  rc = launch_loss_stencil(a, need_grad != 0, stream);
-  if (rc) return rc; }
-  { StageTimer t(ST_REDUCE, stream);
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 3 * N + 1), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials); }
+  if (phases == 3) {
+    { StageTimer t(ST_STENCIL, stream);
+    rc = launch_loss_stencil(a, need_grad != 0, kStencilGather | kStencilSplat, stream);
+    if (rc) return rc; }
+    { StageTimer t(ST_REDUCE, stream);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 3 * N + 1), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials, 0,
+                       (double*)nullptr); }
+    return sfm_last_error();
+  }
+  if (phases & 1) {
+    rc = launch_loss_stencil(a, need_grad != 0, kStencilSplat, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 3 * N), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials, 0,
+                       (double*)nullptr);
+  }
+  if (phases & 2) {
+    if (!e_out) return SFM_ERR_ARG;
+    rc = launch_loss_stencil(a, need_grad != 0, kStencilGather, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 1), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials, 3 * N, e_out);
+  }
+  return sfm_last_error();
+}
+
+extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
+                                const float* params, float* ws, int B, int H, int W, int S, int N,
+                                long long n_elem_global, int need_grad, double* partials, void* stream_) {
+  return loss_forward_phases(3, tgt, src, depth, trans, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
+                             nullptr, stream_);
+}
+
+// The forward in two halves, for a data-parallel step that hides its collectives:
+// _splat writes the 3N splat-side sums of every scale into partials (the [S][3N+1] layout; the min-reprojection
+// slots are left untouched - zero them once), _gather the min-reprojection sums into e_sums[S].  The splat-side
+// all-reduce then runs under the gather-side stencil, the e_sums all-reduce under sfm_loss_backward (which needs only
+// the splat-side sums for the gradients), and sfm_loss_value gives the loss once both have landed.
+extern "C" int sfm_loss_forward_splat(const float* tgt, const float* src, const float* depth, const float* trans,
+                                      const float* params, float* ws, int B, int H, int W, int S, int N,
+                                      long long n_elem_global, int need_grad, double* partials, void* stream_) {
+  return loss_forward_phases(1, tgt, src, depth, trans, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
+                             nullptr, stream_);
+}
+
+extern "C" int sfm_loss_forward_gather(const float* tgt, const float* src, const float* depth, const float* trans,
+                                       const float* params, float* ws, int B, int H, int W, int S, int N,
+                                       long long n_elem_global, int need_grad, double* partials, double* e_sums,
+                                       void* stream_) {
+  return loss_forward_phases(2, tgt, src, depth, trans, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
+                             e_sums, stream_);
+}
+
+// loss (one float) from the global sums; e_sums (may be NULL): the min-reprojection sums if they were reduced apart
+extern "C" int sfm_loss_value(const double* partials, const double* e_sums, int S, int N, long long n_elem_global,
+                              float* loss_out, void* stream_) {
+  if (!partials || !loss_out || S < 1 || N < 2 || N > kMaxSrc || n_elem_global <= 0) return SFM_ERR_ARG;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, partials, S, N, (double)n_elem_global,
+                     loss_out, e_sums);
   return sfm_last_error();
 }
 
@@ -656,7 +720,8 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   if (!need_grad) {  // forward-only step: the loss, and restore the Ovf / flags invariant here
     { StageTimer t(ST_FINALIZE, stream);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, loss_out); }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, loss_out,
+                       (const double*)nullptr); }
     hipLaunchKernelGGL(loss_ovf_clear_kernel, dim3(64, w.n_img), dim3(kBlock), 0, stream, ws + w.Ovf, flags, H * W);
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_img * sizeof(int), stream);
     return e != hipSuccess ? (int)e : sfm_last_error();

@@ -109,7 +109,8 @@ struct StencilArgs {
   float kE;   // 2 / n_elem_global              (coefficient of the min-reprojection term, :168)
 };
 
-// loss_stencil.hip
-int launch_loss_stencil(const StencilArgs& a, bool need_grad, hipStream_t stream);
+// loss_stencil.hip.  which: the gather side (min-reprojection term), the splat side (masked L1 + SSIM terms), or both
+constexpr int kStencilGather = 1, kStencilSplat = 2;
+int launch_loss_stencil(const StencilArgs& a, bool need_grad, int which, hipStream_t stream);
 
 }  // namespace sfm

@@ -396,15 +396,16 @@ __global__ __launch_bounds__(kBlock) void loss_stencil_splat_kernel(StencilArgs 
 
 }  // namespace
 
-int launch_loss_stencil(const StencilArgs& a, bool need_grad, hipStream_t stream) {
+int launch_loss_stencil(const StencilArgs& a, bool need_grad, int which, hipStream_t stream) {
   constexpr int WPB = kBlock / 64;
   const dim3 gs((unsigned)((a.p.n_splat + WPB - 1) / WPB)), gg((unsigned)((a.p.n_gather + WPB - 1) / WPB));
+  const bool gather = (which & kStencilGather) && a.p.n_gather, splat = (which & kStencilSplat) != 0;
   if (need_grad) {
-    if (a.p.n_gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<true>, gg, dim3(kBlock), 0, stream, a);
-    hipLaunchKernelGGL(loss_stencil_splat_kernel<true>, gs, dim3(kBlock), 0, stream, a);
+    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<true>, gg, dim3(kBlock), 0, stream, a);
+    if (splat) hipLaunchKernelGGL(loss_stencil_splat_kernel<true>, gs, dim3(kBlock), 0, stream, a);
   } else {
-    if (a.p.n_gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<false>, gg, dim3(kBlock), 0, stream, a);
-    hipLaunchKernelGGL(loss_stencil_splat_kernel<false>, gs, dim3(kBlock), 0, stream, a);
+    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<false>, gg, dim3(kBlock), 0, stream, a);
+    if (splat) hipLaunchKernelGGL(loss_stencil_splat_kernel<false>, gs, dim3(kBlock), 0, stream, a);
   }
   return sfm_last_error();
 }

@@ -78,7 +78,47 @@ class LossEngine:
         return loss, d_depth, d_pose, d_trans
 
 
+    def step_dp(self, tgt, src, K, depth, pose, trans, n_elem_global: int, process_group=None, need_grad: bool = True,
+                tail: Optional[Tensor] = None):
+        """One data-parallel step with both collectives hidden:
+
+            forward_splat -> all-reduce #1 (3N splat-side sums per scale [+ tail]) || forward_gather
+                          -> all-reduce #2 (min-reprojection sums)                 || backward
+                          -> loss value from the two reduced buffers
+
+        The gradients need only the splat-side sums (kV); the min-reprojection sums only enter the loss VALUE,
+        so their all-reduce can ride under the backward.  ``tail``: extra fp64 scalars summed over the ranks in
+        all-reduce #1 (the regulariser's share of the loss).  Returns (loss, d_depth, d_pose, d_trans, tail)."""
+        import torch.distributed as dist
+        B, H, W, S, N = self.dims
+        n_tail = 0 if tail is None else tail.numel()
+        buf = torch.zeros(self.n_partials + n_tail, dtype=torch.float64, device=self.device)
+        if n_tail:
+            buf[self.n_partials:] = tail
+        e_sums = torch.empty(S, dtype=torch.float64, device=self.device)
+        st = stream_of(tgt)
+        call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
+        call("sfm_loss_forward_splat", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
+             S, N, int(n_elem_global), int(need_grad), ptr(buf), st)
+        h1 = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+        call("sfm_loss_forward_gather", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H,
+             W, S, N, int(n_elem_global), int(need_grad), ptr(buf), ptr(e_sums), st)
+        h2 = dist.all_reduce(e_sums, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+        h1.wait()  # the current stream waits for all-reduce #1 (not the host)
+        loss, d_depth, d_pose, d_trans = self.backward(tgt, src, K, depth, pose, trans, buf, n_elem_global, 1.0, need_grad)
+        h2.wait()
+        call("sfm_loss_value", ptr(buf), ptr(e_sums), S, N, int(n_elem_global), ptr(loss), stream_of(tgt))
+        return loss, d_depth, d_pose, d_trans, (buf[self.n_partials:] if n_tail else None)
+
+
 _engines = {}
+
+
+def _world_size(process_group=None) -> int:
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(process_group)
 
 
 def get_engine(B, H, W, S, N, device) -> LossEngine:
@@ -120,30 +160,40 @@ class _FusedTotalLoss(torch.autograd.Function):
     gradients are computed with the value and scaled by the upstream scalar in ``backward``."""
 
     @staticmethod
-    def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, poses, *maps):
+    def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, overlap, poses,
+                *maps):
         S = n_scales
         pred_depth, pred_exp = list(maps[:S]), list(maps[S:2 * S])
         pred_disp = list(maps[2 * S:3 * S])
         B, H, W, _ = tgt.shape
         N = poses.shape[1]
-        need = any(ctx.needs_input_grad[8:])
+        need = any(ctx.needs_input_grad[9:])
         with torch.cuda.device(tgt.device):
             eng = get_engine(B, H, W, S, N, tgt.device)
             depth = P.pyramid_upsample(pred_depth, H, W).view(S, B, H, W)
             trans = P.pyramid_upsample(pred_exp, H, W)
             n_elem = global_b * H * W * 3
-            # the pixel-loss partial sums and this rank's share of the smoothness term travel in ONE all-reduce
-            buf = torch.zeros(eng.n_partials + 1, dtype=torch.float64, device=tgt.device)
-            g_smooth = None
+            g_smooth, sm = None, None
             if smooth_weight > 0:
                 ws_, wa_ = P.smooth_weights(S, smooth_weight, explain_reg_weight)
                 sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need)
-                buf[-1] = sm
-            eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf[:-1])
-            if global_b != B or process_group is not None:
-                allreduce_partials(buf, process_group)
-            loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf[:-1], n_elem, 1.0, need)
-            total = loss + buf[-1].float()
+            if overlap and _world_size(process_group) > 1:
+                # data parallel, collectives hidden: the splat-side sums and this rank's share of the regulariser
+                # travel in the first all-reduce (under the gather-side stencil), the min-reprojection sums in a
+                # second one (under the backward)
+                loss, d_depth, d_pose, d_trans, tail = eng.step_dp(tgt, src, K, depth, poses, trans, n_elem, process_group,
+                                                                   need, None if sm is None else sm.double().reshape(1))
+                total = loss if tail is None else loss + tail[0].float()
+            else:
+                # one buffer, ONE all-reduce: the S*(3N+1) partial sums and this rank's share of the regulariser
+                buf = torch.zeros(eng.n_partials + 1, dtype=torch.float64, device=tgt.device)
+                if sm is not None:
+                    buf[-1] = sm
+                eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf[:-1])
+                if global_b != B or process_group is not None:
+                    allreduce_partials(buf, process_group)
+                loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf[:-1], n_elem, 1.0, need)
+                total = loss if sm is None else loss + buf[-1].float()
             if need:
                 g_depth = P.pyramid_upsample_grad(d_depth.view(S, B, H, W, 1), [(m.shape[1], m.shape[2]) for m in pred_depth])
                 # the regulariser's gradient of the translation maps is already in place: the adjoint adds to it
@@ -155,21 +205,23 @@ class _FusedTotalLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None,) * 8 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
+        return (None,) * 9 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 
 def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor,
                      pred_depth: Sequence[Tensor], pred_poses: Tensor, pred_exp_logits: Sequence[Tensor],
                      pred_disp: Optional[Sequence[Tensor]] = None, smooth_weight: float = 0.0,
                      explain_reg_weight: float = 0.01, fused: bool = True, process_group=None,
-                     global_batch_size: Optional[int] = None) -> Tensor:
+                     global_batch_size: Optional[int] = None, overlap_collectives: bool = False) -> Tensor:
     """total_loss of SfMLearner_uni.py:75-176 (exp_loss is identically 0 there).
 
     tgt_image [B,H,W,3], src_image_stack [B,H,W,3N] in [-1,1]; intrinsics [B,3,3]
     (``intrinsics[:,0]``, used for every scale, :125); pred_depth[s] [B,h,w,1];
     pred_poses [B,N,6]; pred_exp_logits[s] [B,h,w,3N]; pred_disp[s] for smoothness.
     ``len(pred_depth)`` scales (quirk 1).  Under data parallelism pass the process
-    group (or have torch.distributed initialised) and the loss is the global one."""
+    group (or have torch.distributed initialised) and the loss is the global one:
+    one stream-ordered all-reduce per step, or with ``overlap_collectives`` two hidden ones
+    (``LossEngine.step_dp``: ~46 us of extra launches and stream hand-offs, so only for slow fabrics)."""
     if explain_reg_weight <= 0:
         raise NameError("curr_exp_logits is undefined when explain_reg_weight == 0 (SfMLearner_uni.py:127)")
     tgt = U._check(tgt_image, "tgt_image", 4, 3)
@@ -190,7 +242,7 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
         maps = list(pred_depth) + list(pred_exp_logits) + (list(pred_disp) if smooth_weight > 0 else [])
         maps = [U._check(m, "pyramid map", 4) for m in maps]
         return _FusedTotalLoss.apply(tgt, src, K, process_group, gb, float(smooth_weight), float(explain_reg_weight), S,
-                                     poses, *maps)
+                                     bool(overlap_collectives), poses, *maps)
     smooth = tgt.new_zeros(())
     if smooth_weight > 0:
         for s in range(S):

@@ -1,0 +1,75 @@
+"""The overlapped data-parallel step (LossEngine.step_dp: forward in two halves, two hidden all-reduces, loss from
+sfm_loss_value) against the plain sequence, on ONE GPU with a world-size-1 RCCL group: same kernels, so the results
+must be bit-identical; the collectives run through torch.distributed's nccl backend as they do at N > 1."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import sfm_amd
+from sfm_amd import synth
+from sfm_amd.loss import LossEngine
+from oracle import ref_graph as R
+from helpers import TOL_GRAD, TOL_OUT, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_world1(dev):
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    yield
+    dist.destroy_process_group()
+
+
+def _stacked(g):
+    depth = torch.stack([d.squeeze(3) for d in g["depth"]], 0).contiguous()
+    trans = torch.stack(g["trans"], 0).contiguous()
+    return depth, trans
+
+
+@pytest.mark.parametrize("B,H,W,S,N", [(2, 32, 64, 3, 2), (1, 37, 53, 2, 4)])
+def test_step_dp_equals_plain_step(dev, nccl_world1, B, H, W, S, N):
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=91)
+    g = synth.to_device(inp, dev)
+    depth, trans = _stacked(g)
+    eng = LossEngine(B, H, W, S, N, dev)
+    ne = B * H * W * 3
+    p = eng.forward_partials(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, ne, True)
+    ref = eng.backward(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, p, ne, 1.0, True)
+    tail = torch.tensor([0.125], dtype=torch.float64, device=dev)
+    for _ in range(2):  # twice: the workspace invariants must survive the split sequence
+        out = eng.step_dp(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, ne, None, True, tail)
+        for a, b in zip(out[:4], ref):
+            assert torch.equal(a, b)
+        assert float(out[4][0]) == 0.125
+    torch.cuda.synchronize()
+    assert eng.overflow_state() == (0, 0.0)
+
+
+def test_multi_scale_loss_takes_the_overlapped_path_and_matches_the_oracle(dev, nccl_world1, monkeypatch):
+    """with a (1-rank) group and the world size reported as 2, multi_scale_loss goes through step_dp"""
+    import sfm_amd.loss as L
+    monkeypatch.setattr(L, "_world_size", lambda pg=None: 2)
+    inp = synth.make_inputs(2, 32, 64, S=3, N=2, seed=92, full_res=False)
+    do = [d.clone().requires_grad_(True) for d in inp["depth"]]
+    to = [t.clone().requires_grad_(True) for t in inp["trans"]]
+    po = inp["pose"].clone().requires_grad_(True)
+    lo = R.multi_scale_loss(inp["tgt"], inp["src"], inp["K"], do, po, to, pred_disp=inp["disp"], smooth_weight=0.01)
+    lo.backward()
+    g = synth.to_device(inp, dev)
+    dg = [d.requires_grad_(True) for d in g["depth"]]
+    tg = [t.requires_grad_(True) for t in g["trans"]]
+    pg = g["pose"].requires_grad_(True)
+    lg = sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], dg, pg, tg, pred_disp=g["disp"], smooth_weight=0.01,
+                                  global_batch_size=2, overlap_collectives=True)
+    lg.backward()
+    assert rel_err(lg, lo) <= TOL_OUT
+    assert rel_err(pg.grad, po.grad) <= TOL_GRAD
+    for s in range(3):
+        assert rel_err(tg[s].grad, to[s].grad) <= TOL_GRAD
