@@ -513,6 +513,30 @@ def dilated_conv3x3(x_nhwc: Tensor, w_hwio: Tensor, rate: int) -> Tensor:
     return F.conv2d(x, w, padding=rate, dilation=rate).permute(0, 2, 3, 1).contiguous()
 
 
+def batch_norm_elu(x_nhwc: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Optional[Tensor] = None,
+                   moving_var: Optional[Tensor] = None, decay: float = 0.9997, epsilon: float = 1e-5) -> Tensor:
+    """``slim.batch_norm(x, decay, epsilon, scale=True, fused=True, is_training=True, updates_collections=None)``
+    followed by ``tf.nn.elu`` - what the arg-scope of ``disp_aspp_u_dense`` (nets.py:653-656 ->
+    resnet/resnet_utils.py:232-251) appends to every ``slim.conv2d``.  Training mode: batch statistics over
+    (B, H, W), population variance for the normalisation; the moving averages (updated in place) take the
+    variance with Bessel's correction, as ``tf.nn.fused_batch_norm`` does.                      ASSUMPTION"""
+    c = x_nhwc.shape[-1]
+    flat = x_nhwc.reshape(-1, c)
+    mean = flat.mean(dim=0)
+    var = ((flat - mean) ** 2).mean(dim=0)
+    # moving_averages.assign_moving_average(zero_debias=False): variable -= (variable - value) * cast(1.0 - decay)
+    f = torch.tensor(1.0 - decay, dtype=x_nhwc.dtype)
+    if moving_mean is not None:
+        with torch.no_grad():
+            moving_mean.sub_((moving_mean - mean.detach()) * f)
+    if moving_var is not None:
+        with torch.no_grad():
+            m = flat.shape[0]
+            moving_var.sub_((moving_var - var.detach() * (m / max(m - 1, 1))) * f)
+    z = gamma * ((x_nhwc - mean) * torch.rsqrt(var + epsilon)) + beta
+    return F.elu(z)
+
+
 # ----------------------------------------------------------------------------
 # data-parallel decomposition of the pixel loss (SURVEY.md section 8e)
 # ----------------------------------------------------------------------------

@@ -58,6 +58,9 @@ SIGNATURES = {
     "sfm_resize_bilinear_bwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_smooth_workspace_floats": [_P, _P, _P, _I, _I],
     "sfm_smooth_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
+    "sfm_bn_elu_workspace_floats": [_LL, _I],
+    "sfm_bn_elu_fwd": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P],
+    "sfm_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P],
     "sfm_prof_enable": [_I],
     "sfm_prof_stages": [],
     "sfm_prof_read": [_P],

@@ -3,8 +3,10 @@ the ``slim.conv2d(x, out_channels, [3, 3], rate=r)`` calls at :457, :458, :463) 
 
 ``dilated_conv3x3(x, w, rate)`` is the convolution itself - NHWC activations, HWIO weights, SAME
 padding, stride 1, fp32 - forward and backward (data and weights) through the C ABI
-(``sfm_aspp_conv3x3_*``, csrc/aspp.hip).  The normaliser / activation slim applies after it
-(batch norm + ELU from the arg-scope, nets.py:653-656) are outside this operator.
+(``sfm_aspp_conv3x3_*``, csrc/aspp.hip).  ``batch_norm_elu`` is the normaliser + activation the
+arg-scope appends to it (``slim.batch_norm`` in training mode, then ``tf.nn.elu``; nets.py:653-656,
+resnet/resnet_utils.py:232-251; csrc/bn_elu.hip), and ``conv2d_bn_elu`` chains the two: what one
+``slim.conv2d(x, C, [3, 3], rate=r)`` of ``disp_bottleneck_dense`` computes.
 """
 from __future__ import annotations
 
@@ -73,3 +75,68 @@ def dilated_conv3x3(x: Tensor, w: Tensor, rate: int) -> Tensor:
         raise ValueError("rate must be >= 1")
     _same_device(x, w)
     return _DilatedConv3x3.apply(x, w, int(rate))
+
+
+BN_DECAY = 0.9997    # args.batch_norm_decay, SfMLearner_uni.py:19
+BN_EPSILON = 1e-5    # args.batch_norm_epsilon, SfMLearner_uni.py:20
+
+
+class _BatchNormElu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, decay, epsilon):
+        C = x.shape[-1]
+        M = x.numel() // C
+        lib = _lib.load()
+        n_ws = lib.sfm_bn_elu_workspace_floats(M, C)
+        if n_ws < 0:
+            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4 with C/4 dividing 256)")
+        with torch.cuda.device(x.device):
+            ws = torch.empty(n_ws // 2 + 1, dtype=torch.float64, device=x.device)  # fp64 partials: 8-byte aligned
+            y = torch.empty_like(x)
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            call("sfm_bn_elu_fwd", ptr(x), ptr(gamma), ptr(beta), M, C, float(epsilon), float(decay), ptr(moving_mean),
+                 ptr(moving_var), ptr(y), ptr(mean), ptr(invstd), ptr(ws), stream_of(x))
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.mark_non_differentiable(mean, invstd)
+        return y, mean, invstd
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gi):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        C = x.shape[-1]
+        M = x.numel() // C
+        gy = gy.contiguous()
+        with torch.cuda.device(x.device):
+            ws = torch.empty(_lib.load().sfm_bn_elu_workspace_floats(M, C) // 2 + 1, dtype=torch.float64, device=x.device)
+            gx = torch.empty_like(x)
+            ggamma = torch.empty_like(gamma)
+            gbeta = torch.empty_like(gamma)
+            call("sfm_bn_elu_bwd", ptr(x), ptr(y), ptr(gy), ptr(gamma), ptr(mean), ptr(invstd), M, C, ptr(gx), ptr(ggamma),
+                 ptr(gbeta), ptr(ws), stream_of(x))
+        return gx, ggamma, gbeta, None, None, None, None
+
+
+def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor = None, moving_var: Tensor = None,
+                   decay: float = BN_DECAY, epsilon: float = BN_EPSILON) -> Tensor:
+    """``tf.nn.elu(slim.batch_norm(x, decay, epsilon, scale=True, fused=True, is_training=True,
+    updates_collections=None))`` - the normaliser + activation of the ASPP arg-scope (nets.py:653-656).
+    x [..., C] NHWC; gamma, beta [C]; moving_mean / moving_var [C] are updated in place when given."""
+    x = _check(x, "x", x.dim() if isinstance(x, torch.Tensor) else 4)
+    C = x.shape[-1]
+    gamma = _check(gamma, "gamma", 1, C)
+    beta = _check(beta, "beta", 1, C)
+    for name, t in (("moving_mean", moving_mean), ("moving_var", moving_var)):
+        if t is not None:
+            _check(t, name, 1, C)
+            if not t.is_contiguous():
+                raise ValueError(f"{name} is updated in place: it must be contiguous")
+    _same_device(x, gamma, beta, moving_mean, moving_var)
+    return _BatchNormElu.apply(x, gamma, beta, moving_mean, moving_var, float(decay), float(epsilon))[0]
+
+
+def conv2d_bn_elu(x: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, rate: int, moving_mean: Tensor = None,
+                  moving_var: Tensor = None, decay: float = BN_DECAY, epsilon: float = BN_EPSILON) -> Tensor:
+    """One ``slim.conv2d(x, Cout, [3, 3], rate=rate)`` of ``disp_bottleneck_dense`` under its arg-scope
+    (nets.py:457, 458, 463): dilated convolution (no bias: a normaliser is set), batch norm, ELU."""
+    return batch_norm_elu(dilated_conv3x3(x, w, rate), gamma, beta, moving_mean, moving_var, decay, epsilon)

@@ -1,0 +1,238 @@
+// The normaliser + activation slim appends to every slim.conv2d of disp_bottleneck_dense (nets.py:455-470) through the
+// arg-scope of disp_aspp_u_dense (nets.py:653-656 -> resnet/resnet_utils.py:232-251): slim.batch_norm(decay, epsilon,
+// scale=True, center=True, fused=True, is_training=True, updates_collections=None) followed by tf.nn.elu
+// (SURVEY.md section 8f row 3).  x is the convolution's output, [M, C] with M = B*H*W rows (NHWC).  Per channel:
+//
+//   mean = E[x]            var = E[(x - mean)^2]   (population variance: what fused_batch_norm normalises with)
+//   xhat = (x - mean) rsqrt(var + eps)             z = gamma xhat + beta            y = z > 0 ? z : exp(z) - 1
+//   moving_mean -= (moving_mean - mean) * fp32(1 - decay) ;  moving_var likewise with var M / (M - 1)   (in place;
+//   moving_averages.assign_moving_average: the factor 1 - decay is formed in double on the host, then cast)
+//
+// and the adjoint (TF autodiff: EluGrad on the activations, FusedBatchNormGrad):
+//
+//   dz = gy (y < 0 ? y + 1 : 1)      gbeta = sum dz      ggamma = sum dz xhat
+//   gx = gamma rsqrt(var + eps) (dz - gbeta / M - xhat ggamma / M)
+//
+// HBM-bound elementwise work around two per-channel reductions.  Reductions: a workgroup sums a chunk of rows in fp64
+// (lanes own 4 adjacent channels, so every load is a coalesced float4), chunk partials are added in chunk order by the
+// finalising kernel: no atomics, reproducible.  Forward = stats + finalise + apply (x is read twice); backward = sums +
+// finalise + apply.
+#include "sfm_device.h"
+#include "sfm_internal.h"
+
+namespace sfm {
+namespace {
+
+struct BnPlan {
+  int groups;      // C / 4 channel groups of a row
+  int row_lanes;   // kBlock / groups: rows a workgroup reads per iteration
+  long rows_per_chunk;
+  int chunks;
+};
+
+static inline bool bn_plan(long M, int C, BnPlan& p) {
+  if (M < 1 || C < 4 || C % 4) return false;
+  p.groups = C / 4;
+  if (p.groups > kBlock || kBlock % p.groups) return false;
+  p.row_lanes = kBlock / p.groups;
+  long chunks = (M + p.row_lanes - 1) / p.row_lanes;  // at least one iteration each
+  if (chunks > 512) chunks = 512;
+  p.rows_per_chunk = ((M + chunks - 1) / chunks + p.row_lanes - 1) / p.row_lanes * p.row_lanes;
+  p.chunks = (int)((M + p.rows_per_chunk - 1) / p.rows_per_chunk);
+  return true;
+}
+
+__device__ __forceinline__ float elu_grad_from_y(float y) { return y < 0.0f ? y + 1.0f : 1.0f; }
+
+// part [chunks][2][C] (fp64): MODE 0: (sum x, sum x^2 about `shift`);  MODE 1: (sum dz, sum dz xhat)
+// The forward sums are taken about a per-channel shift (the channel's first row) so that E[d^2] - E[d]^2 does not cancel.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ gy,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, long M, int C, BnPlan p,
+                                                            double* __restrict__ part) {
+  __shared__ double red[kBlock][8];
+  const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
+  const long r0 = (long)blockIdx.x * p.rows_per_chunk, r1 = min(M, r0 + p.rows_per_chunk);
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = s4, i4 = s4;
+  if (MODE == 0) s4 = *reinterpret_cast<const float4*>(x + 4 * g);  // row 0 of the channel group: the shift
+  else {
+    m4 = *reinterpret_cast<const float4*>(mean + 4 * g);
+    i4 = *reinterpret_cast<const float4*>(invstd + 4 * g);
+  }
+  for (long r = r0 + rl; r < r1; r += p.row_lanes) {
+    const size_t o = (size_t)r * C + 4 * g;
+    const float4 xv = *reinterpret_cast<const float4*>(x + o);
+    if (MODE == 0) {
+      const float d0 = xv.x - s4.x, d1 = xv.y - s4.y, d2 = xv.z - s4.z, d3 = xv.w - s4.w;
+      a[0] += d0; a[1] += d1; a[2] += d2; a[3] += d3;
+      b[0] += (double)d0 * d0; b[1] += (double)d1 * d1; b[2] += (double)d2 * d2; b[3] += (double)d3 * d3;
+    } else {
+      const float4 yv = *reinterpret_cast<const float4*>(y + o), gv = *reinterpret_cast<const float4*>(gy + o);
+      const float z0 = gv.x * elu_grad_from_y(yv.x), z1 = gv.y * elu_grad_from_y(yv.y);
+      const float z2 = gv.z * elu_grad_from_y(yv.z), z3 = gv.w * elu_grad_from_y(yv.w);
+      a[0] += z0; a[1] += z1; a[2] += z2; a[3] += z3;
+      b[0] += (double)(z0 * ((xv.x - m4.x) * i4.x)); b[1] += (double)(z1 * ((xv.y - m4.y) * i4.y));
+      b[2] += (double)(z2 * ((xv.z - m4.z) * i4.z)); b[3] += (double)(z3 * ((xv.w - m4.w) * i4.w));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = a[k]; red[threadIdx.x][4 + k] = b[k]; }
+  __syncthreads();
+  if (rl == 0) {
+    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    for (int j = 0; j < p.row_lanes; ++j)  // fixed order
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { sa[k] += red[j * p.groups + g][k]; sb[k] += red[j * p.groups + g][4 + k]; }
+    double* o = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[4 * g + k] = sa[k]; o[C + 4 * g + k] = sb[k]; }
+  }
+}
+
+// one WAVE per channel: lanes stride over the chunk partials, then a shuffle tree (a fixed order) -> statistics (and the
+// moving averages) / parameter gradients.  grid: ceil(C / 4) workgroups of 4 waves.
+__device__ __forceinline__ void bn_chunk_sums(const double* __restrict__ part, int C, int chunks, int c, double& s, double& q) {
+  const int lane = threadIdx.x & 63;
+  s = 0.0; q = 0.0;
+  for (int k = lane; k < chunks; k += 64) { s += part[(size_t)k * 2 * C + c]; q += part[(size_t)k * 2 * C + C + c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); q += __shfl_down(q, o, 64); }
+}
+
+__global__ __launch_bounds__(kBlock) void bn_finalize_fwd_kernel(const double* __restrict__ part, const float* __restrict__ x,
+                                                                 long M, int C, int chunks, float eps, float one_minus_decay,
+                                                                 float* __restrict__ moving_mean,
+                                                                 float* __restrict__ moving_var,
+                                                                 float* __restrict__ save_mean,
+                                                                 float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s, q;
+  bn_chunk_sums(part, C, chunks, c, s, q);
+  if ((threadIdx.x & 63) != 0) return;
+  const double md = s / (double)M;                       // mean of (x - shift)
+  const double var = fmax(q / (double)M - md * md, 0.0);  // population variance
+  const double mean = (double)x[c] + md;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (moving_mean) moving_mean[c] = moving_mean[c] - (moving_mean[c] - (float)mean) * one_minus_decay;
+  if (moving_var) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    moving_var[c] = moving_var[c] - (moving_var[c] - (float)unbiased) * one_minus_decay;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bn_finalize_bwd_kernel(const double* __restrict__ part, int C, int chunks,
+                                                                 float* __restrict__ ggamma, float* __restrict__ gbeta) {
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s, q;
+  bn_chunk_sums(part, C, chunks, c, s, q);
+  if ((threadIdx.x & 63) != 0) return;
+  gbeta[c] = (float)s;
+  ggamma[c] = (float)q;
+}
+
+__device__ __forceinline__ float elu(float z) { return z > 0.0f ? z : expf(z) - 1.0f; }
+
+// one thread per float4 of x
+__global__ __launch_bounds__(kBlock) void bn_elu_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, long n4, int groups,
+                                                              float* __restrict__ y) {
+  const long e = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n4) return;
+  const int g = (int)(e % groups);
+  const float4 xv = reinterpret_cast<const float4*>(x)[e];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[g], be = reinterpret_cast<const float4*>(beta)[g];
+  const float4 m = reinterpret_cast<const float4*>(mean)[g], is = reinterpret_cast<const float4*>(invstd)[g];
+  float4 o;
+  o.x = elu(ga.x * ((xv.x - m.x) * is.x) + be.x);
+  o.y = elu(ga.y * ((xv.y - m.y) * is.y) + be.y);
+  o.z = elu(ga.z * ((xv.z - m.z) * is.z) + be.z);
+  o.w = elu(ga.w * ((xv.w - m.w) * is.w) + be.w);
+  reinterpret_cast<float4*>(y)[e] = o;
+}
+
+__global__ __launch_bounds__(kBlock) void bn_elu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const float* __restrict__ gy,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ ggamma,
+                                                                  const float* __restrict__ gbeta, long n4, int groups,
+                                                                  float inv_m, float* __restrict__ gx) {
+  const long e = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n4) return;
+  const int g = (int)(e % groups);
+  const float4 xv = reinterpret_cast<const float4*>(x)[e], yv = reinterpret_cast<const float4*>(y)[e];
+  const float4 gv = reinterpret_cast<const float4*>(gy)[e];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[g];
+  const float4 m = reinterpret_cast<const float4*>(mean)[g], is = reinterpret_cast<const float4*>(invstd)[g];
+  const float4 gg = reinterpret_cast<const float4*>(ggamma)[g], gb = reinterpret_cast<const float4*>(gbeta)[g];
+  auto one = [&](float xs, float ys, float gs, float gam, float mu, float iv, float dgam, float dbet) {
+    const float dz = gs * elu_grad_from_y(ys);
+    const float xh = (xs - mu) * iv;
+    return gam * iv * (dz - dbet * inv_m - xh * (dgam * inv_m));
+  };
+  float4 o;
+  o.x = one(xv.x, yv.x, gv.x, ga.x, m.x, is.x, gg.x, gb.x);
+  o.y = one(xv.y, yv.y, gv.y, ga.y, m.y, is.y, gg.y, gb.y);
+  o.z = one(xv.z, yv.z, gv.z, ga.z, m.z, is.z, gg.z, gb.z);
+  o.w = one(xv.w, yv.w, gv.w, ga.w, m.w, is.w, gg.w, gb.w);
+  reinterpret_cast<float4*>(gx)[e] = o;
+}
+
+}  // namespace
+}  // namespace sfm
+
+using namespace sfm;
+
+// scratch of both calls: the chunk partials [chunks][2][C] in fp64, counted in floats
+extern "C" long long sfm_bn_elu_workspace_floats(long long M, int C) {
+  BnPlan p;
+  if (!bn_plan((long)M, C, p)) return SFM_ERR_ARG;
+  return (long long)p.chunks * 2 * C * 2 + 4;
+}
+
+extern "C" int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* beta, long long M, int C, float eps, double decay,
+                              float* moving_mean, float* moving_var, float* y, float* save_mean, float* save_invstd,
+                              float* ws, void* stream_) {
+  BnPlan p;
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || !bn_plan((long)M, C, p) || !(eps > 0.0f))
+    return SFM_ERR_ARG;
+  if (((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;  // fp64 partials
+  hipStream_t stream = (hipStream_t)stream_;
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks), dim3(kBlock), 0, stream, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, part);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, x, (long)M, C,
+                     p.chunks, eps, (float)(1.0 - decay), moving_mean, moving_var, save_mean, save_invstd);
+  const long n4 = (long)M * p.groups;
+  hipLaunchKernelGGL(bn_elu_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, gamma, beta,
+                     save_mean, save_invstd, n4, p.groups, y);
+  return sfm_last_error();
+}
+
+extern "C" int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
+                              const float* save_invstd, long long M, int C, float* gx, float* ggamma, float* gbeta,
+                              float* ws, void* stream_) {
+  BnPlan p;
+  if (!x || !y || !gy || !gamma || !save_mean || !save_invstd || !gx || !ggamma || !gbeta || !ws || !bn_plan((long)M, C, p))
+    return SFM_ERR_ARG;
+  if (((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
+                     p, part);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma,
+                     gbeta);
+  const long n4 = (long)M * p.groups;
+  hipLaunchKernelGGL(bn_elu_bwd_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, y, gy,
+                     gamma, save_mean, save_invstd, ggamma, gbeta, n4, p.groups, (float)(1.0 / (double)M), gx);
+  return sfm_last_error();
+}

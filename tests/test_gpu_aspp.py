@@ -88,3 +88,55 @@ def test_full_size_layers_of_config5(dev, h, w_, Cin, Cout, rate):
     yg.backward(go.to(dev))
     assert rel_err(yg, yo) <= TOL
     assert rel_err(wg.grad, wo.grad) <= TOL
+
+
+# ---------------------------------------------------------------- batch norm + ELU
+@pytest.mark.parametrize("shape", [(2, 8, 26, 512), (1, 16, 52, 256), (8, 128, 416, 32), (3, 7, 5, 64), (2, 5, 3, 1024),
+                                   (1, 1, 1, 32)])
+def test_batch_norm_elu_matches_oracle(dev, shape):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(*shape, generator=g) * 1.5 + 0.7      # off-centre: the variance must not cancel
+    C = shape[-1]
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    gy = torch.randn(*shape, generator=g)
+    mm_o, mv_o = torch.zeros(C), torch.ones(C)
+    xo, go, bo = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yo = R.batch_norm_elu(xo, go, bo, mm_o, mv_o)
+    yo.backward(gy)
+    mm_g, mv_g = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    xg, gg, bg = (t.to(dev).requires_grad_(True) for t in (x, gamma, beta))
+    yg = sfm_amd.batch_norm_elu(xg, gg, bg, mm_g, mv_g)
+    yg.backward(gy.to(dev))
+    M = x.numel() // C
+    if M > 1:
+        assert rel_err(yg, yo) <= 1e-5
+        assert rel_err(xg.grad, xo.grad) <= 1e-4
+        assert rel_err(gg.grad, go.grad) <= 1e-4
+        assert rel_err(mv_g, mv_o) <= 1e-5
+    assert rel_err(bg.grad, bo.grad) <= 1e-4
+    assert rel_err(mm_g, mm_o) <= 1e-5
+
+
+def test_conv2d_bn_elu_is_one_slim_conv2d(dev):
+    """slim.conv2d(x, 64, [3, 3], rate=3) under the ASPP arg-scope = dilated conv -> batch norm -> ELU"""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 12, 20, 128, generator=g)
+    w = torch.randn(3, 3, 128, 64, generator=g) / (3 * 128 ** 0.5)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo = R.batch_norm_elu(R.dilated_conv3x3(xo, wo, 3), gamma, beta)
+    yo.square().sum().backward()
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    yg = sfm_amd.conv2d_bn_elu(xg, wg, gamma.to(dev), beta.to(dev), 3)
+    yg.square().sum().backward()
+    assert rel_err(yg, yo) <= 1e-5
+    assert rel_err(xg.grad, xo.grad) <= 1e-4
+    assert rel_err(wg.grad, wo.grad) <= 1e-4
+
+
+def test_batch_norm_elu_rejects_bad_shapes(dev):
+    with pytest.raises(ValueError):
+        sfm_amd.batch_norm_elu(torch.zeros(1, 2, 2, 6, device=dev), torch.ones(6, device=dev), torch.zeros(6, device=dev))
+    with pytest.raises(TypeError):
+        sfm_amd.batch_norm_elu(torch.zeros(1, 2, 2, 32), torch.ones(32), torch.zeros(32))

@@ -33,3 +33,23 @@ for h, w_, ci, co, rates in LAYERS:
         print(f"{h}x{w_} {ci}->{co} r{r}: " + "  ".join(f"{k} {v*1e6:7.1f} us {fl/v/1e12:6.1f} TF" for k, v in t.items()), flush=True)
 print("total: " + "  ".join(f"{k} {v*1e3:.3f} ms {flops_total/v/1e12:.1f} TF" for k, v in tot.items()),
       f" all {sum(tot.values())*1e3:.3f} ms {3*flops_total/sum(tot.values())/1e12:.1f} TF (peak 157.3)")
+
+# batch norm + ELU after each convolution (csrc/bn_elu.hip): HBM-bound; algorithmic bytes = x in + y out (forward),
+# x, y, gy in + gx out (backward); the kernels read x twice (statistics, then apply) and x, y, gy twice in the backward
+print("batch norm + ELU (slim arg-scope epilogue), per conv output:")
+tot_f = tot_b = 0.0
+for h, w_, ci, co, rates in LAYERS:
+    x = torch.randn(B, h, w_, co, device=dev, requires_grad=True)
+    gamma = torch.ones(co, device=dev, requires_grad=True); beta = torch.zeros(co, device=dev, requires_grad=True)
+    gy = torch.randn(B, h, w_, co, device=dev)
+    y = sfm_amd.batch_norm_elu(x, gamma, beta)
+    tf_ = timeit(lambda: sfm_amd.batch_norm_elu(x, gamma, beta))
+    def fb():
+        x.grad = None
+        sfm_amd.batch_norm_elu(x, gamma, beta).backward(gy)
+    tb_ = timeit(fb) - tf_
+    nbytes = x.numel() * 4
+    tot_f += tf_ * len(rates); tot_b += tb_ * len(rates)
+    print(f"{h}x{w_} C={co}: fwd {tf_*1e6:7.1f} us {2*nbytes/tf_/1e9:7.0f} GB/s algorithmic   bwd {tb_*1e6:7.1f} us {4*nbytes/tb_/1e9:7.0f} GB/s algorithmic"
+          f"   ({nbytes/1e6:.1f} MB per tensor; through the Python mirror, allocations included)")
+print(f"all 11 epilogues: fwd {tot_f*1e3:.3f} ms  bwd {tot_b*1e3:.3f} ms")
