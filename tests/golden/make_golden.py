@@ -77,8 +77,44 @@ def c1_fixture():
     return dict(out=npy(out), mask=npy(mask), idx=npy(torch.cat(ints, dim=3)).astype(np.int16), input_sums=sums)
 
 
+def pyramid_fixture():
+    """SURVEY.md 8f rows 1-3: raw disparity pyramid -> normalise -> depth; bilinear upsample; smoothness regulariser;
+    batch norm + ELU.  Inputs, outputs and gradients (against the stored upstream weights)."""
+    g = torch.Generator().manual_seed(105)
+    B, H, W, S, N = 2, 16, 24, 3, 2
+    out = dict(dims=np.array([B, H, W, S, N]))
+    raw = [(10.0 * torch.sigmoid(torch.randn(B, H >> s, W >> s, 1, generator=g)) + 0.01).requires_grad_(True) for s in range(S)]
+    exp = [(0.01 * torch.randn(B, H >> s, W >> s, 3 * N, generator=g)).requires_grad_(True) for s in range(S)]
+    dn, dp = R.normalize_disp(raw)
+    up_d = [R.resize_bilinear_tf1(d, H, W) for d in dp]
+    up_e = [R.resize_bilinear_tf1(e, H, W) for e in exp]
+    sm = sum(0.01 / 2 ** s * R.compute_smooth_loss(dn[s]) + 0.01 / 2 ** s * (R.compute_smooth_loss(exp[s]) + exp[s].abs().mean())
+             for s in range(S))
+    wd = [torch.randn(B, H, W, 1, generator=g) for _ in range(S)]
+    we = [torch.randn(B, H, W, 3 * N, generator=g) for _ in range(S)]
+    (sm + sum((a * b).sum() for a, b in zip(up_d, wd)) * 1e-3 + sum((a * b).sum() for a, b in zip(up_e, we)) * 1e-3).backward()
+    out["smooth"] = npy(sm)
+    for s in range(S):
+        out[f"raw{s}"], out[f"exp{s}"] = npy(raw[s]), npy(exp[s])
+        out[f"dispn{s}"], out[f"depth{s}"] = npy(dn[s]), npy(dp[s])
+        out[f"up_depth{s}"], out[f"up_exp{s}"] = npy(up_d[s]), npy(up_e[s])
+        out[f"wd{s}"], out[f"we{s}"] = npy(wd[s]), npy(we[s])
+        out[f"d_raw{s}"], out[f"d_exp{s}"] = npy(raw[s].grad), npy(exp[s].grad)
+    x = (torch.randn(2, 6, 10, 32, generator=g) * 1.5 + 0.7).requires_grad_(True)
+    gamma = (torch.rand(32, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(32, generator=g) * 0.3).requires_grad_(True)
+    gy = torch.randn(2, 6, 10, 32, generator=g)
+    mm, mv = torch.zeros(32), torch.ones(32)
+    y = R.batch_norm_elu(x, gamma, beta, mm, mv)
+    y.backward(gy)
+    out.update(bn_x=npy(x), bn_gamma=npy(gamma), bn_beta=npy(beta), bn_gy=npy(gy), bn_y=npy(y), bn_mm=npy(mm), bn_mv=npy(mv),
+               bn_d_x=npy(x.grad), bn_d_gamma=npy(gamma.grad), bn_d_beta=npy(beta.grad))
+    return out
+
+
 def main():
     torch.set_num_threads(4)
+    np.savez_compressed(os.path.join(HERE, "pyramid_bn_2x16x24.npz"), **pyramid_fixture())
     np.savez_compressed(os.path.join(HERE, "warp_2x16x24.npz"), **warp_fixture(2, 16, 24, 101, 0.05))
     np.savez_compressed(os.path.join(HERE, "warp_3x13x17_oob.npz"), **warp_fixture(3, 13, 17, 102, 0.2))
     np.savez_compressed(os.path.join(HERE, "loss_2x16x24_s2n2.npz"), **loss_fixture(2, 16, 24, 2, 2, 103, 0.02, True))

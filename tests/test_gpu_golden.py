@@ -84,3 +84,35 @@ def test_golden_c1_bilinear_project_forward(dev):
     assert rel_err(out, _t(g["out"], dev)) <= TOL_OUT and rel_err(mask, _t(g["mask"], dev)) <= TOL_OUT
     out2, mask2 = sfm_amd.projective_warp(d["tgt"], d["depth"], d["pose"], d["K"], add_trans=True, translations=d["trans"])
     assert rel_err(out2, _t(g["out"], dev)) <= TOL_OUT and rel_err(mask2, _t(g["mask"], dev)) <= TOL_OUT
+
+
+def test_golden_pyramid_and_bn(dev):
+    """SURVEY.md 8f rows 1-3 against committed numbers: normalise -> upsample -> regulariser, and batch norm + ELU."""
+    g = np.load(os.path.join(GOLD, "pyramid_bn_2x16x24.npz"))
+    B, H, W, S, N = (int(v) for v in g["dims"])
+    raw = [_t(g[f"raw{s}"], dev).requires_grad_(True) for s in range(S)]
+    exp = [_t(g[f"exp{s}"], dev).requires_grad_(True) for s in range(S)]
+    dn, dp = sfm_amd.normalize_disp(raw)
+    up_d = [sfm_amd.resize_bilinear(d, H, W) for d in dp]
+    up_e = [sfm_amd.resize_bilinear(e, H, W) for e in exp]
+    for s in range(S):
+        assert rel_err(dn[s], _t(g[f"dispn{s}"], dev)) <= TOL_OUT and rel_err(dp[s], _t(g[f"depth{s}"], dev)) <= TOL_OUT
+        assert rel_err(up_d[s], _t(g[f"up_depth{s}"], dev)) <= TOL_OUT
+        assert np.array_equal(up_e[s].detach().cpu().numpy(), g[f"up_exp{s}"]), "same fp32 op order: bit-exact"
+    sm = sum(0.01 / 2 ** s * sfm_amd.compute_smooth_loss(dn[s])
+             + 0.01 / 2 ** s * (sfm_amd.compute_smooth_loss(exp[s]) + exp[s].abs().mean()) for s in range(S))
+    assert rel_err(sm, _t(g["smooth"], dev)) <= TOL_OUT
+    tot = sm + 1e-3 * sum((a * _t(g[f"wd{s}"], dev)).sum() for s, a in enumerate(up_d)) \
+        + 1e-3 * sum((a * _t(g[f"we{s}"], dev)).sum() for s, a in enumerate(up_e))
+    tot.backward()
+    for s in range(S):
+        assert rel_err(raw[s].grad, _t(g[f"d_raw{s}"], dev)) <= TOL_GRAD, f"d_raw{s}"
+        assert rel_err(exp[s].grad, _t(g[f"d_exp{s}"], dev)) <= TOL_GRAD, f"d_exp{s}"
+    x, gamma, beta = (_t(g[k], dev).requires_grad_(True) for k in ("bn_x", "bn_gamma", "bn_beta"))
+    mm, mv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+    y = sfm_amd.batch_norm_elu(x, gamma, beta, mm, mv)
+    y.backward(_t(g["bn_gy"], dev))
+    assert rel_err(y, _t(g["bn_y"], dev)) <= TOL_OUT
+    assert rel_err(mm, _t(g["bn_mm"], dev)) <= TOL_OUT and rel_err(mv, _t(g["bn_mv"], dev)) <= TOL_OUT
+    for leaf, k in ((x, "bn_d_x"), (gamma, "bn_d_gamma"), (beta, "bn_d_beta")):
+        assert rel_err(leaf.grad, _t(g[k], dev)) <= TOL_GRAD, k

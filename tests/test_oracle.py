@@ -225,3 +225,75 @@ def test_golden_c1_config0():
     assert np.array_equal(torch.cat(ints, dim=3).numpy().astype(np.int16), g["idx"])
     out, mask = R.bilinear_project(c["tgt"], coords, use_depth=True, depth=z)
     assert rel_err(out, torch.from_numpy(g["out"])) < 1e-6 and rel_err(mask, torch.from_numpy(g["mask"])) < 1e-6
+
+
+# ------------------------------------------------------------------ (5) the pyramid steps and the ASPP epilogue
+def test_resize_x2_known_answer():
+    """TF-1 legacy resize (align_corners=False, no half-pixel centres), x2: even outputs copy, odd outputs average the
+    two neighbours, the last one clamps."""
+    x = torch.arange(12, dtype=torch.float32).reshape(1, 3, 4, 1) ** 2
+    y = R.resize_bilinear_tf1(x, 6, 8)
+    assert torch.equal(y[0, ::2, ::2, 0], x[0, :, :, 0])
+    assert torch.equal(y[0, 0, 1::2, 0][:-1], (x[0, 0, :-1, 0] + x[0, 0, 1:, 0]) / 2)
+    assert torch.equal(y[0, 0, -1, 0], x[0, 0, -1, 0]) and torch.equal(y[0, -1, 0, 0], x[0, -1, 0, 0])
+    assert torch.equal(R.resize_bilinear_tf1(x, 3, 4), x)
+
+
+def test_smooth_loss_known_answer():
+    """p = a x^2 + b y: |dx| = a (2x + 1), dy = b, dx2 = 2a, every mixed / dy2 term 0."""
+    a, b, h, w = 0.5, -0.25, 5, 7
+    xs = torch.arange(w, dtype=torch.float32)
+    p = (a * xs ** 2)[None, None, :, None] + (b * torch.arange(h, dtype=torch.float32))[None, :, None, None]
+    p = p.expand(2, h, w, 3).contiguous()
+    want = 0.25 * (float((a * (2 * xs[:-1] + 1)).mean()) + abs(b)) + 0.75 * (2 * a)
+    assert abs(float(R.compute_smooth_loss(p)) - want) < 1e-6
+
+
+def test_normalize_disp_known_answer():
+    d = [torch.rand(2, 4, 6, 1) + 0.5, torch.rand(2, 2, 3, 1) + 0.5]
+    dn, dp = R.normalize_disp(d)
+    for u, v in zip(dn, dp):
+        assert torch.allclose(u.mean(dim=(1, 2, 3)), torch.ones(2), atol=1e-6)
+        assert torch.equal(v, 1.0 / u)
+
+
+def test_batch_norm_elu_against_torch_functional():
+    """independent implementation: F.batch_norm(training) + F.elu; momentum = 1 - decay; running_var is unbiased"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 7, 8, generator=g) * 2 + 1
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g)
+    mm, mv = torch.zeros(8), torch.ones(8)
+    y = R.batch_norm_elu(x, gamma, beta, mm, mv, decay=0.9, epsilon=1e-5)
+    rm, rv = torch.zeros(8), torch.ones(8)
+    y2 = F.elu(F.batch_norm(x.permute(0, 3, 1, 2), rm, rv, gamma, beta, True, 0.1, 1e-5)).permute(0, 2, 3, 1)
+    assert rel_err(y, y2) < 1e-5 and rel_err(mm, rm) < 1e-5 and rel_err(mv, rv) < 1e-5
+
+
+def test_gradcheck_pyramid_ops():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 3, 4, 2, generator=g, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda t: R.resize_bilinear_tf1(t, 7, 9), (x,), eps=1e-6, atol=1e-6)
+    d = (torch.rand(2, 3, 4, 1, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t: torch.cat([v.flatten() for v in sum(R.normalize_disp([t]), [])]), (d,),
+                                    eps=1e-6, atol=1e-6)
+    gam = (torch.rand(2, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    bet = torch.randn(2, generator=g, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda a, b, c: R.batch_norm_elu(a, b, c), (x, gam, bet), eps=1e-6, atol=1e-5)
+
+
+def test_golden_pyramid_and_bn():
+    g = np.load(os.path.join(GOLD, "pyramid_bn_2x16x24.npz"))
+    B, H, W, S, N = (int(v) for v in g["dims"])
+    raw = [torch.from_numpy(g[f"raw{s}"]) for s in range(S)]
+    exp = [torch.from_numpy(g[f"exp{s}"]) for s in range(S)]
+    dn, dp = R.normalize_disp(raw)
+    for s in range(S):
+        assert rel_err(dn[s], torch.from_numpy(g[f"dispn{s}"])) < 1e-6
+        assert np.array_equal(R.resize_bilinear_tf1(torch.from_numpy(g[f"depth{s}"]), H, W).numpy(), g[f"up_depth{s}"])
+        assert np.array_equal(R.resize_bilinear_tf1(exp[s], H, W).numpy(), g[f"up_exp{s}"])
+    sm = sum(0.01 / 2 ** s * R.compute_smooth_loss(dn[s]) + 0.01 / 2 ** s * (R.compute_smooth_loss(exp[s]) + exp[s].abs().mean())
+             for s in range(S))
+    assert abs(float(sm) - float(g["smooth"])) <= 1e-6 * abs(float(g["smooth"]))
+    y = R.batch_norm_elu(torch.from_numpy(g["bn_x"]), torch.from_numpy(g["bn_gamma"]), torch.from_numpy(g["bn_beta"]))
+    assert rel_err(y, torch.from_numpy(g["bn_y"])) < 1e-6
