@@ -343,12 +343,15 @@ __global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __rest
 // ------------------------------------------------------------------ finalize
 // partials (global sums) -> loss and the coefficient the backward warp scales the SSIM part of Hb with:
 // kV(s, i) = (1 - alpha) (M / n) (-1/2) [clip passes] / n   (d/dSp of (1-alpha) mean(m) clip((1 - V/n)/2, 0, 1)).
-__device__ __forceinline__ float loss_kv(const double* __restrict__ partials, int N, int s, int i, double n_elem) {
+// Every workgroup of the backward evaluates this: products with 1 / n instead of fp64 divisions (a V * (1/n) that differs
+// from V / n in the last bit of a double rounds to the same float except on an exact tie; `pass` only matters when the
+// mean SSIM leaves [-1, 1], which it cannot).
+__device__ __forceinline__ float loss_kv(const double* __restrict__ partials, int N, int s, int i, double inv_n) {
   const int nterm = 3 * N + 1;
   const double M = partials[s * nterm + 3 * i + 1], V = partials[s * nterm + 3 * i + 2];
-  const float h = (1.0f - (float)(V / n_elem)) / 2.0f;
+  const float h = (1.0f - (float)(V * inv_n)) / 2.0f;
   const double pass = (h >= 0.0f && h <= 1.0f) ? 1.0 : 0.0;
-  return (float)((1.0 - (double)kAlpha) * (M / n_elem) * (-0.5) * pass / n_elem);
+  return (float)((1.0 - (double)kAlpha) * (M * inv_n) * (-0.5) * pass * inv_n);
 }
 
 __device__ __forceinline__ float loss_value(const double* __restrict__ partials, int S, int N, double n_elem,
@@ -393,7 +396,8 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                const float* __restrict__ Hb,
                                                                const float* __restrict__ dG,
                                                                const double* __restrict__ partials, double n_elem,
-                                                               float gl, float* __restrict__ loss_out, LossDims d,
+                                                               double inv_n, float gl, float* __restrict__ loss_out,
+                                                               LossDims d,
                                                                float step_x, float step_y, int tiles_x, int tiles_y,
                                                                float* __restrict__ d_depth,
                                                                float* __restrict__ d_trans,
@@ -418,7 +422,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     ps[i] = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-    kv[i] = gl * loss_kv(partials, N, s, i, n_elem);  // wave-uniform (scalar loads)
+    kv[i] = gl * loss_kv(partials, N, s, i, inv_n);  // wave-uniform (scalar loads)
     clr[i] = flags[(s * N + i) * d.B + b] != 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) dp[i][k] = 0.0f;
@@ -730,7 +734,8 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   const dim3 grid((unsigned)((long)S * B * w.nblk_bwd));
 #define SFM_LAUNCH_BWD(NSRC)                                                                                          \
   hipLaunchKernelGGL(loss_warp_bwd_kernel<NSRC>, grid, dim3(kBlock), 0, stream, tgt, src, depth, trans, params,      \
-                     ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, gloss, loss_out, d, sfm_lin_step(W),       \
+                     ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, 1.0 / (double)n_elem_global, gloss,       \
+                     loss_out, d, sfm_lin_step(W),                                                                   \
                      sfm_lin_step(H), w.btiles_x, w.btiles_y,                                                        \
                      d_depth, d_trans, ws + w.dPp, ws + w.Ovf, flags)
   if (N == 2) SFM_LAUNCH_BWD(2); else if (N == 3) SFM_LAUNCH_BWD(3); else SFM_LAUNCH_BWD(4);

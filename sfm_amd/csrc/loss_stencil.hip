@@ -242,8 +242,8 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
     if (r + 1 <= r_last) step(r + 1, IC<1>{});
     if (r + 2 <= r_last) step(r + 2, IC<2>{});
   }
-  sA = wave_sum(sA); sM = wave_sum(sM); sV = wave_sum(sV);
-  if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sA, sM, sV, 0.f);
+  sA = wave_sum_dpp_lane63(sA); sM = wave_sum_dpp_lane63(sM); sV = wave_sum_dpp_lane63(sV);
+  if (lane == 63) *reinterpret_cast<float4*>(wavep_out) = make_float4(sA, sM, sV, 0.f);
 }
 
 // ------------------------------------------------------------------ gather side
@@ -376,8 +376,8 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
     if (r + 1 <= r_last) step(r + 1, IC<1>{});
     if (r + 2 <= r_last) step(r + 2, IC<2>{});
   }
-  sE = wave_sum(sE);
-  if (lane == 0) *reinterpret_cast<float4*>(wavep_out) = make_float4(sE, 0.f, 0.f, 0.f);
+  sE = wave_sum_dpp_lane63(sE);
+  if (lane == 63) *reinterpret_cast<float4*>(wavep_out) = make_float4(sE, 0.f, 0.f, 0.f);
 }
 
 // One wave per work item, 4 independent waves per block (plain round-robin block order: the

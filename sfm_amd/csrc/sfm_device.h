@@ -178,6 +178,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Wave sum on the DPP network (6 VALU instructions with a cross-lane operand each; the shuffle tree above goes through
+// ds_bpermute: an LDS round trip per step).  Lane 63 ends up with the total.  Order: quads, rows of 16 by rotation,
+// then row 0 -> 1, 2 -> 3 and rows {0,1} -> {2,3} by broadcast; fixed, so results are reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float x) {  // 0 where the source lane is invalid or the row is masked off
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp_lane63(float v) {
+  v += dpp_mov<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124, 0xf>(v);  // row_ror:4
+  v += dpp_mov<0x128, 0xf>(v);  // row_ror:8   -> every lane holds its row's sum
+  v += dpp_mov<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_mov<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+  return v;
+}
+
 // Sum NV per-thread values over a 256-thread block; thread k < NV of wave 0 ends
 // up holding the k-th total and stores it to out[k].  red must hold 4*NV floats.
 template <int NV>
@@ -186,8 +203,8 @@ __device__ __forceinline__ void block_sum_store(float* __restrict__ vals, float*
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    float s = wave_sum(vals[k]);
-    if (lane == 0) red[wave * NV + k] = s;
+    float s = wave_sum_dpp_lane63(vals[k]);
+    if (lane == 63) red[wave * NV + k] = s;
   }
   __syncthreads();
   if (threadIdx.x < NV) {
