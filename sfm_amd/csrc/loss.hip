@@ -562,8 +562,11 @@ struct StageTimer {
 };
 
 static inline bool dims_ok(const LossDims& d) {
-  return d.B > 0 && d.H > 0 && d.W > 0 && d.S > 0 && d.N >= 2 && d.N <= kMaxSrc && d.B <= 65535 && d.S <= 65535 &&
-         (long)d.S * d.N * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 8 ? 3 * d.N : 8);
+  if (!(d.B > 0 && d.H > 0 && d.W > 0 && d.S > 0 && d.N >= 2 && d.N <= kMaxSrc && d.B <= 65535 && d.S <= 65535 &&
+        (long)d.S * d.N * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 8 ? 3 * d.N : 8)))
+    return false;
+  const StencilPlan sp = stencil_plan(d, 8);  // the smallest rows per wave = the most work items (32-bit in the kernels)
+  return sp.n_splat + sp.n_gather < 2147483647L;
 }
 
 // Tuning knob (experiments only): image rows per stencil wave; 0 = the heuristic of stencil_plan.

@@ -84,12 +84,15 @@ using IC = std::integral_constant<int, V>;
 struct Item {
   int img, chunk, strip;
 };
+// 32-bit arithmetic (the item count is checked on the host): a 64-bit division pair here was ~7 % of a wave's instructions
 __device__ __forceinline__ Item split_item(long item, const StencilPlan& p) {
+  const unsigned u = (unsigned)item, strips = (unsigned)p.strips, chunks = (unsigned)p.chunks;
   Item it;
-  it.strip = (int)(item % p.strips);
-  const long r = item / p.strips;
-  it.chunk = (int)(r % p.chunks);
-  it.img = (int)(r / p.chunks);
+  const unsigned r = u / strips;
+  it.strip = (int)(u - r * strips);
+  const unsigned q = r / chunks;
+  it.chunk = (int)(r - q * chunks);
+  it.img = (int)q;
   return it;
 }
 
@@ -166,16 +169,24 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
       const float inv = col_in ? fast_rcp(ca.w + 1e-10f) : 0.f;
       Iv[S0] = inv;
       const float xv[3] = {ca.x * inv, ca.y * inv, ca.z * inv}, yv[3] = {cs.x, cs.y, cs.z};  // 0 outside the image
+      // all products first, then all cross-lane sums: a DPP operand needs two wait states after the VALU write of
+      // its source, and the compiler pads with s_nop when the product is formed right in front of its hsum3
+      float sq[3], xy[3], nz[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         X[S0][ch] = xv[ch];
         Y[S0][ch] = yv[ch];
+        sq[ch] = xv[ch] * xv[ch] + yv[ch] * yv[ch];
+        xy[ch] = xv[ch] * yv[ch];
+        nz[ch] = (xv[ch] == 0.0f) ? 0.0f : 1.0f;
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
         Hm[S0][ch][0] = hsum3(xv[ch]);
         Hm[S0][ch][1] = hsum3(yv[ch]);
-        Hm[S0][ch][2] = hsum3(xv[ch] * xv[ch] + yv[ch] * yv[ch]);
-        Hm[S0][ch][3] = hsum3(xv[ch] * yv[ch]);
-        const float nz = (xv[ch] == 0.0f) ? 0.0f : 1.0f;
-        Nz[S0][ch] = nz + (lane_left(nz) + lane_right(nz));
+        Hm[S0][ch][2] = hsum3(sq[ch]);
+        Hm[S0][ch][3] = hsum3(xy[ch]);
+        Nz[S0][ch] = nz[ch] + (lane_left(nz[ch]) + lane_right(nz[ch]));
       }
     } else {
       Iv[S0] = 0.f;
@@ -192,6 +203,7 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
       const bool pix_in = q >= 0 && q < d.H && col_in;
       const bool own = own_col && q >= y0 && q < y1;
       const float rcnt = 1.0f / (rows_in(q, d.H) * nx);  // k * fl(1/k) == 1 exactly for k = 4, 6, 9
+      float cf[3][3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         float ca_ = 0.f, cb_ = 0.f, cc_ = 0.f;
@@ -206,11 +218,17 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
           sA += m * fabsf(X[S1][ch] - Y[S1][ch]);
           sM += m;
         }
-        if constexpr (GRAD) {  // coefficients of row q overwrite those of row q - 3 (same slot)
-          Ch[S1][ch][0] = hsum3(pix_in ? ca_ : 0.f);
-          Ch[S1][ch][1] = hsum3(pix_in ? cb_ : 0.f);
-          Ch[S1][ch][2] = hsum3(pix_in ? cc_ : 0.f);
+        if constexpr (GRAD) {
+          cf[ch][0] = pix_in ? ca_ : 0.f;
+          cf[ch][1] = pix_in ? cb_ : 0.f;
+          cf[ch][2] = pix_in ? cc_ : 0.f;
         }
+      }
+      if constexpr (GRAD) {  // coefficients of row q overwrite those of row q - 3 (same slot); sums after all values (DPP hazard)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) Ch[S1][ch][m] = hsum3(cf[ch][m]);
       }
     }
     // ---- row p = r - 2: backward seeds (coefficient rows p-1, p, p+1 sit in slots S0, S2, S1)
@@ -304,17 +322,25 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
     const float x0[3] = {n0.x, n0.y, n0.z}, x1[3] = {n1.x, n1.y, n1.z}, t[3] = {nt.x, nt.y, nt.z};
     if (r + 1 <= r_last) fetch(r + 1);
     if (r >= 0 && r < d.H) {
+      float pr[3][4];  // products first, cross-lane sums after (DPP hazard: see splat_item)
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         X0[S0][ch] = x0[ch]; X1[S0][ch] = x1[ch]; T[S0][ch] = t[ch];
         const float tt = t[ch] * t[ch];
+        pr[ch][0] = x0[ch] * x0[ch] + tt;
+        pr[ch][1] = x1[ch] * x1[ch] + tt;
+        pr[ch][2] = x0[ch] * t[ch];
+        pr[ch][3] = x1[ch] * t[ch];
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
         Hm[S0][ch][0] = hsum3(t[ch]);
         Hm[S0][ch][1] = hsum3(x0[ch]);
         Hm[S0][ch][2] = hsum3(x1[ch]);
-        Hm[S0][ch][3] = hsum3(x0[ch] * x0[ch] + tt);
-        Hm[S0][ch][4] = hsum3(x1[ch] * x1[ch] + tt);
-        Hm[S0][ch][5] = hsum3(x0[ch] * t[ch]);
-        Hm[S0][ch][6] = hsum3(x1[ch] * t[ch]);
+        Hm[S0][ch][3] = hsum3(pr[ch][0]);
+        Hm[S0][ch][4] = hsum3(pr[ch][1]);
+        Hm[S0][ch][5] = hsum3(pr[ch][2]);
+        Hm[S0][ch][6] = hsum3(pr[ch][3]);
       }
     } else {
 #pragma unroll
@@ -328,6 +354,7 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
     if (r - r_first >= 2) {
       const bool pix_in = q >= 0 && q < d.H && col_in;
       const bool own = own_col && q >= y0 && q < y1;
+      float cf[3][6];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         float mm[7];
@@ -344,9 +371,15 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
         if constexpr (GRAD) {
           const float u0 = (pix_in && first) ? ku * clip01_half_pass(v0) : 0.f;
           const float u1 = (pix_in && !first) ? ku * clip01_half_pass(v1) : 0.f;
-          Ch[S1][ch][0] = hsum3(a0 * u0); Ch[S1][ch][1] = hsum3(b0 * u0); Ch[S1][ch][2] = hsum3(c0 * u0);
-          Ch[S1][ch][3] = hsum3(a1 * u1); Ch[S1][ch][4] = hsum3(b1 * u1); Ch[S1][ch][5] = hsum3(c1 * u1);
+          cf[ch][0] = a0 * u0; cf[ch][1] = b0 * u0; cf[ch][2] = c0 * u0;
+          cf[ch][3] = a1 * u1; cf[ch][4] = b1 * u1; cf[ch][5] = c1 * u1;
         }
+      }
+      if constexpr (GRAD) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+          for (int m = 0; m < 6; ++m) Ch[S1][ch][m] = hsum3(cf[ch][m]);
       }
     }
     if constexpr (GRAD) {
