@@ -172,7 +172,9 @@ int sfm_pyramid_upsample_fwd(const float* const* in, const int* h, const int* w,
 long long sfm_pyramid_upsample_bwd_workspace_floats(const int* h, const int* w, int S, int B, int C, int H, int W);
 int sfm_pyramid_upsample_bwd(const float* gout, const int* h, const int* w, int S, int B, int C, int H, int W,
                              int accumulate, float* const* gin, float* ws, void* stream);
-/* the same for one map */
+/* the same for one map; here C may also be any multiple of 4 (the x2 upsample of disp_bottleneck_dense's feature
+ * maps, nets.py:454, 465); ws of _bwd: sfm_resize_bilinear_bwd_workspace_floats(...) floats, 16-byte aligned */
+long long sfm_resize_bilinear_bwd_workspace_floats(int B, int h, int w, int C, int H, int W);
 int sfm_resize_bilinear_fwd(const float* in, int B, int h, int w, int C, int H, int W, float* out, void* stream);
 int sfm_resize_bilinear_bwd(const float* gout, int B, int h, int w, int C, int H, int W, float* gin, float* ws,
                             void* stream);
@@ -204,23 +206,33 @@ int sfm_aspp_conv3x3_bwd_data(const float* gout, const float* w, int B, int H, i
 int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, int rate,
                                 float* gw, float* ws, void* stream);
 
+/* The 1x1 convolutions of the same block (nets.py:455, 456, 461, 466, 470): slim.conv2d(x, Cout, [1, 1]) itself, w
+ * [1,1,Cin,Cout], through the same implicit-GEMM kernels (centre tap only).  ws: the 3x3 workspace of the shape. */
+int sfm_aspp_conv1x1_fwd(const float* in, const float* w, int B, int H, int W, int Cin, int Cout, float* out, float* ws,
+                         void* stream);
+int sfm_aspp_conv1x1_bwd_data(const float* gout, const float* w, int B, int H, int W, int Cin, int Cout, float* gin,
+                              float* ws, void* stream);
+int sfm_aspp_conv1x1_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, float* gw,
+                                float* ws, void* stream);
+
 /* ---- batch norm + ELU after each ASPP convolution -----------------------------------
  * What the arg-scope of disp_aspp_u_dense (nets.py:653-656 -> resnet/resnet_utils.py:232-251) appends to every
  * slim.conv2d of disp_bottleneck_dense (nets.py:455-470): slim.batch_norm(decay, epsilon, scale=True, fused=True,
  * is_training=True, updates_collections=None) then tf.nn.elu.  x [M, C] = the convolution's output (M = B*H*W rows,
- * NHWC; C a multiple of 4 with C/4 dividing 256), gamma / beta [C].  Training mode: batch statistics (population
+ * NHWC; C a multiple of 4, at most 1024), gamma / beta [C].  Training mode: batch statistics (population
  * variance), saved in save_mean / save_invstd [C] for the backward; moving_mean / moving_var [C] (may be NULL) are
  * updated in place as assign_moving_average does: m -= (m - batch) * fp32(1 - decay), the variance with Bessel's
  * correction (fused_batch_norm).  Reductions in a fixed order.
  * ws: sfm_bn_elu_workspace_floats(M, C) floats, 8-byte aligned, undefined between calls.
+ * act = 1: ELU; act = 0: the batch norm alone (the slim.conv2d(..., activation_fn=None) calls, nets.py:455, 470).
  * Backward: gy = dL/dy -> gx [M, C], ggamma [C], gbeta [C] (TF autodiff: EluGrad, FusedBatchNormGrad). */
 long long sfm_bn_elu_workspace_floats(long long M, int C);
 int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* beta, long long M, int C, float eps, double decay,
-                   float* moving_mean, float* moving_var, float* y, float* save_mean, float* save_invstd, float* ws,
-                   void* stream);
+                   int act, float* moving_mean, float* moving_var, float* y, float* save_mean, float* save_invstd,
+                   float* ws, void* stream);
 int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
-                   const float* save_invstd, long long M, int C, float* gx, float* ggamma, float* gbeta, float* ws,
-                   void* stream);
+                   const float* save_invstd, long long M, int C, int act, float* gx, float* ggamma, float* gbeta,
+                   float* ws, void* stream);
 
 /* ---- measurement aid (no counterpart in the reference; used by bench.py only) -----------
  * When enabled, sfm_loss_forward / sfm_loss_backward bracket each of their launches with

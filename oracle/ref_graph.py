@@ -514,7 +514,8 @@ def dilated_conv3x3(x_nhwc: Tensor, w_hwio: Tensor, rate: int) -> Tensor:
 
 
 def batch_norm_elu(x_nhwc: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Optional[Tensor] = None,
-                   moving_var: Optional[Tensor] = None, decay: float = 0.9997, epsilon: float = 1e-5) -> Tensor:
+                   moving_var: Optional[Tensor] = None, decay: float = 0.9997, epsilon: float = 1e-5,
+                   activation: bool = True) -> Tensor:
     """``slim.batch_norm(x, decay, epsilon, scale=True, fused=True, is_training=True, updates_collections=None)``
     followed by ``tf.nn.elu`` - what the arg-scope of ``disp_aspp_u_dense`` (nets.py:653-656 ->
     resnet/resnet_utils.py:232-251) appends to every ``slim.conv2d``.  Training mode: batch statistics over
@@ -534,7 +535,36 @@ def batch_norm_elu(x_nhwc: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Opt
             m = flat.shape[0]
             moving_var.sub_((moving_var - var.detach() * (m / max(m - 1, 1))) * f)
     z = gamma * ((x_nhwc - mean) * torch.rsqrt(var + epsilon)) + beta
-    return F.elu(z)
+    return F.elu(z) if activation else z
+
+
+def conv1x1(x_nhwc: Tensor, w_hwio: Tensor) -> Tensor:
+    """``slim.conv2d(x, Cout, [1, 1])`` without normaliser / activation (nets.py:455, 456, 461, 466, 470)."""
+    return x_nhwc @ w_hwio[0, 0]
+
+
+def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Optional[Tensor] = None, rates=(2, 4),
+                          use_skip: bool = True, use_skip2: bool = True, skip2: Optional[Tensor] = None):
+    """nets.py:451-471 op for op; every slim.conv2d = convolution (no bias) + batch norm (training) [+ ELU unless
+    activation_fn=None] through the arg-scope of nets.py:653-656.  ``params`` as in sfm_amd.aspp."""
+    def sc(x, name, rate=None, activation=True):
+        q = params[name]
+        y = conv1x1(x, q["w"]) if rate is None else dilated_conv3x3(x, q["w"], rate)
+        return batch_norm_elu(y, q["gamma"], q["beta"], activation=activation)
+    h, w = concat.shape[1], concat.shape[2]
+    upnet = sc(resize_bilinear_tf1(concat, 2 * h, 2 * w), "up", activation=False)
+    supnet = sc(upnet, "sup")
+    aspp_up = sc(upnet, "aspp_up", rate=rates[0])
+    aspp_up2 = sc(torch.cat([supnet, aspp_up], dim=3), "aspp_up2", rate=rates[1])
+    if use_skip:
+        q = params["skip_bn"]
+        skip = sc(batch_norm_elu(skip_feat, q["gamma"], q["beta"]), "skip")
+    else:
+        skip = sc(torch.cat([aspp_up, aspp_up2], dim=3), "skip", rate=rates[1] * 2)
+    parts = [supnet, aspp_up, aspp_up2, skip]
+    if use_skip2:
+        parts.append(sc(resize_bilinear_tf1(skip2, 2 * h, 2 * w), "skip2"))
+    return sc(torch.cat(parts, dim=3), "out", activation=False), upnet
 
 
 # ----------------------------------------------------------------------------

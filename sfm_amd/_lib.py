@@ -54,13 +54,17 @@ SIGNATURES = {
     "sfm_pyramid_upsample_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "sfm_pyramid_upsample_bwd_workspace_floats": [_P, _P, _I, _I, _I, _I, _I],
     "sfm_pyramid_upsample_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_resize_bilinear_bwd_workspace_floats": [_I, _I, _I, _I, _I, _I],
     "sfm_resize_bilinear_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "sfm_resize_bilinear_bwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_smooth_workspace_floats": [_P, _P, _P, _I, _I],
     "sfm_smooth_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
+    "sfm_aspp_conv1x1_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_aspp_conv1x1_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_aspp_conv1x1_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_bn_elu_workspace_floats": [_LL, _I],
-    "sfm_bn_elu_fwd": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P],
-    "sfm_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P],
+    "sfm_bn_elu_fwd": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P, _P],
+    "sfm_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P],
     "sfm_prof_enable": [_I],
     "sfm_prof_stages": [],
     "sfm_prof_read": [_P],

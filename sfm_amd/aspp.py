@@ -83,21 +83,22 @@ BN_EPSILON = 1e-5    # args.batch_norm_epsilon, SfMLearner_uni.py:20
 
 class _BatchNormElu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, decay, epsilon):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, decay, epsilon, act):
         C = x.shape[-1]
         M = x.numel() // C
         lib = _lib.load()
         n_ws = lib.sfm_bn_elu_workspace_floats(M, C)
         if n_ws < 0:
-            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4 with C/4 dividing 256)")
+            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4, at most 1024)")
         with torch.cuda.device(x.device):
             ws = torch.empty(n_ws // 2 + 1, dtype=torch.float64, device=x.device)  # fp64 partials: 8-byte aligned
             y = torch.empty_like(x)
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty_like(mean)
-            call("sfm_bn_elu_fwd", ptr(x), ptr(gamma), ptr(beta), M, C, float(epsilon), float(decay), ptr(moving_mean),
+            call("sfm_bn_elu_fwd", ptr(x), ptr(gamma), ptr(beta), M, C, float(epsilon), float(decay), int(act), ptr(moving_mean),
                  ptr(moving_var), ptr(y), ptr(mean), ptr(invstd), ptr(ws), stream_of(x))
         ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.act = int(act)
         ctx.mark_non_differentiable(mean, invstd)
         return y, mean, invstd
 
@@ -112,16 +113,17 @@ class _BatchNormElu(torch.autograd.Function):
             gx = torch.empty_like(x)
             ggamma = torch.empty_like(gamma)
             gbeta = torch.empty_like(gamma)
-            call("sfm_bn_elu_bwd", ptr(x), ptr(y), ptr(gy), ptr(gamma), ptr(mean), ptr(invstd), M, C, ptr(gx), ptr(ggamma),
+            call("sfm_bn_elu_bwd", ptr(x), ptr(y), ptr(gy), ptr(gamma), ptr(mean), ptr(invstd), M, C, ctx.act, ptr(gx), ptr(ggamma),
                  ptr(gbeta), ptr(ws), stream_of(x))
-        return gx, ggamma, gbeta, None, None, None, None
+        return gx, ggamma, gbeta, None, None, None, None, None
 
 
 def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor = None, moving_var: Tensor = None,
-                   decay: float = BN_DECAY, epsilon: float = BN_EPSILON) -> Tensor:
+                   decay: float = BN_DECAY, epsilon: float = BN_EPSILON, activation: bool = True) -> Tensor:
     """``tf.nn.elu(slim.batch_norm(x, decay, epsilon, scale=True, fused=True, is_training=True,
     updates_collections=None))`` - the normaliser + activation of the ASPP arg-scope (nets.py:653-656).
-    x [..., C] NHWC; gamma, beta [C]; moving_mean / moving_var [C] are updated in place when given."""
+    x [..., C] NHWC; gamma, beta [C]; moving_mean / moving_var [C] are updated in place when given.
+    ``activation=False``: the batch norm alone (``slim.conv2d(..., activation_fn=None)``, nets.py:455, 470)."""
     x = _check(x, "x", x.dim() if isinstance(x, torch.Tensor) else 4)
     C = x.shape[-1]
     gamma = _check(gamma, "gamma", 1, C)
@@ -132,7 +134,7 @@ def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor =
             if not t.is_contiguous():
                 raise ValueError(f"{name} is updated in place: it must be contiguous")
     _same_device(x, gamma, beta, moving_mean, moving_var)
-    return _BatchNormElu.apply(x, gamma, beta, moving_mean, moving_var, float(decay), float(epsilon))[0]
+    return _BatchNormElu.apply(x, gamma, beta, moving_mean, moving_var, float(decay), float(epsilon), bool(activation))[0]
 
 
 def conv2d_bn_elu(x: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, rate: int, moving_mean: Tensor = None,
@@ -140,3 +142,80 @@ def conv2d_bn_elu(x: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, rate: int, 
     """One ``slim.conv2d(x, Cout, [3, 3], rate=rate)`` of ``disp_bottleneck_dense`` under its arg-scope
     (nets.py:457, 458, 463): dilated convolution (no bias: a normaliser is set), batch norm, ELU."""
     return batch_norm_elu(dilated_conv3x3(x, w, rate), gamma, beta, moving_mean, moving_var, decay, epsilon)
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        B, H, W, Cin = x.shape
+        Cout = w.shape[3]
+        with torch.cuda.device(x.device):
+            ws = _workspace(B, H, W, Cin, Cout, x.device)
+            out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+            call("sfm_aspp_conv1x1_fwd", ptr(x), ptr(w), B, H, W, Cin, Cout, ptr(out), ptr(ws), stream_of(x))
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, w = ctx.saved_tensors
+        B, H, W, Cin = x.shape
+        Cout = w.shape[3]
+        gout = gout.contiguous()
+        gx = gw = None
+        with torch.cuda.device(x.device):
+            ws = _workspace(B, H, W, Cin, Cout, x.device)
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                call("sfm_aspp_conv1x1_bwd_data", ptr(gout), ptr(w), B, H, W, Cin, Cout, ptr(gx), ptr(ws), stream_of(x))
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty_like(w)
+                call("sfm_aspp_conv1x1_bwd_weight", ptr(x), ptr(gout), B, H, W, Cin, Cout, ptr(gw), ptr(ws), stream_of(x))
+        return gx, gw
+
+
+def conv1x1(x: Tensor, w: Tensor) -> Tensor:
+    """``slim.conv2d(x, w.shape[3], [1, 1])`` without normaliser / activation / bias: x [B,H,W,Cin], w [1,1,Cin,Cout]
+    (nets.py:455, 456, 461, 466, 470).  Channels must be multiples of 32."""
+    x = _check(x, "x", 4)
+    w = _check(w, "w", 4)
+    if w.shape[0] != 1 or w.shape[1] != 1 or w.shape[2] != x.shape[3]:
+        raise ValueError(f"w must be [1, 1, {x.shape[3]}, Cout], got {tuple(w.shape)}")
+    _same_device(x, w)
+    return _Conv1x1.apply(x, w)
+
+
+def _slim_conv(x, p, name, rate=None, activation=True):
+    """one slim.conv2d of the block under its arg-scope: p[name] = dict(w, gamma, beta[, moving_mean, moving_var])"""
+    q = p[name]
+    y = conv1x1(x, q["w"]) if rate is None else dilated_conv3x3(x, q["w"], rate)
+    return batch_norm_elu(y, q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"), activation=activation)
+
+
+def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None, rates=(2, 4), use_skip: bool = True,
+                          use_skip2: bool = True, skip2: Tensor = None):
+    """``nets.disp_bottleneck_dense`` (nets.py:451-471), one decoder level of ``disp_aspp_u_dense``, every op a
+    hand-written kernel: x2 bilinear upsample, 1x1 and dilated 3x3 convolutions on fp32 MFMA, batch norm (training) +
+    ELU; ``torch.cat`` only moves data.  ``params``: name -> dict(w, gamma, beta[, moving_mean, moving_var]) for
+    'up' (:455), 'sup' (:456), 'aspp_up' (:457), 'aspp_up2' (:458), 'skip' (:461 or :463), ['skip2' (:466)], 'out'
+    (:470) and, with use_skip, 'skip_bn' = dict(gamma, beta, ...) for the batch norm of the skip feature (:460).
+    ``skip_feat`` = end_points[skip_block].  Returns (xconcat, upnet) like the reference."""
+    from .pyramid import resize_bilinear
+    h, w = concat.shape[1], concat.shape[2]
+    upnet = resize_bilinear(concat, 2 * h, 2 * w)                                        # :454
+    upnet = _slim_conv(upnet, params, "up", activation=False)                            # :455
+    supnet = _slim_conv(upnet, params, "sup")                                            # :456
+    aspp_up = _slim_conv(upnet, params, "aspp_up", rate=rates[0])                        # :457
+    aspp_up2 = _slim_conv(torch.cat([supnet, aspp_up], dim=3), params, "aspp_up2", rate=rates[1])   # :458
+    if use_skip:
+        q = params["skip_bn"]
+        skip = batch_norm_elu(skip_feat, q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"))   # :460
+        skip = _slim_conv(skip, params, "skip")                                          # :461
+    else:
+        skip = _slim_conv(torch.cat([aspp_up, aspp_up2], dim=3), params, "skip", rate=rates[1] * 2)   # :463
+    parts = [supnet, aspp_up, aspp_up2, skip]
+    if use_skip2:
+        s2 = resize_bilinear(skip2, 2 * h, 2 * w)                                        # :465
+        parts.append(_slim_conv(s2, params, "skip2"))                                    # :466
+    xconcat = _slim_conv(torch.cat(parts, dim=3), params, "out", activation=False)       # :470
+    return xconcat, upnet

@@ -243,7 +243,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
     mma_step<TM, TN>(As, Bs, LDA, LDB, wm0, wn0, acc);
     __syncthreads();
   }
-  float* o = gw + ((long)blockIdx.z * 9 + tap) * Cin * Cout;
+  float* o = gw + ((long)blockIdx.z * gridDim.y + tap) * Cin * Cout;  // gridDim.y taps: 9, or 1 for a 1x1 convolution
   store_acc<TM, TN>(acc, o, Cout, ci0 + wm0, Cin, co0 + wn0);
 }
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void aspp_flip_kernel(const float* __restri
   __shared__ float tile[32][33];
   const int t = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((long)(8 - t) * Cin + ci0 + r) * Cout + co0 + tx];
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((long)((int)gridDim.z - 1 - t) * Cin + ci0 + r) * Cout + co0 + tx];
   __syncthreads();
   for (int r = ty; r < 32; r += 8) wt[((long)t * Cout + co0 + r) * Cin + ci0 + tx] = tile[tx][r];
 }
@@ -445,10 +445,10 @@ struct WgradPlan {
   long pps;  // pixels per split, multiple of BK
 };
 
-static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, int rate) {
+static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, int rate, int ntaps = 9) {
   const long M = (long)B * H * W;
   WgradPlan p;
-  if (Cin % 64 == 0 && (Cin % 128 != 0 || Cout % 64 != 0) && rate <= kSegMaxRate && W >= BK) {
+  if (ntaps == 9 && Cin % 64 == 0 && (Cin % 128 != 0 || Cout % 64 != 0) && rate <= kSegMaxRate && W >= BK) {
     p.cfg = 4; p.bm = 64; p.bn = 32;
     const long nsteps = (long)B * H * ((W + BK - 1) / BK), base = (long)(Cin / 64) * (Cout / 32);
     long splits = (768 + base - 1) / base;               // ~3 workgroups of 3 waves per CU
@@ -461,7 +461,7 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, int rate) {
   else if (Cin % 128 == 0 && Cout % 64 == 0) { p.cfg = 1; p.bm = 128; p.bn = 64; }
   else if (Cin % 64 == 0) { p.cfg = 2; p.bm = 64; p.bn = 32; }
   else { p.cfg = 3; p.bm = 32; p.bn = 32; }
-  const long base = (long)(Cin / p.bm) * (Cout / p.bn) * 9;
+  const long base = (long)(Cin / p.bm) * (Cout / p.bn) * ntaps;
   long splits = (512 + base - 1) / base;
   const long max_splits = (M + 8 * BK - 1) / (8 * BK);  // at least 8 K-steps per split
   if (splits > max_splits) splits = max_splits;
@@ -477,10 +477,13 @@ static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
          (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 40);
 }
 
+// ntaps = 9: the dilated 3x3; ntaps = 1: a 1x1 convolution = the same kernels on the centre tap alone (rate 0 makes every
+// tap offset zero, the weights are [1][Cin][Cout]).
 static int launch_conv(const float* in, const float* wt, float* out, float* slabs, int B, int H, int W, int Cin, int Cout,
-                       int rate, hipStream_t stream) {
+                       int rate, hipStream_t stream, int ntaps = 9) {
   const long M = (long)B * H * W;
-  const ConvPlan p = conv_plan(M, Cin, Cout);
+  ConvPlan p = conv_plan(M, Cin, Cout);
+  if (ntaps == 1) { p.splits = 1; p.tps = 1; rate = 0; }
   float* dst = p.splits > 1 ? slabs : out;
   const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), Cout / p.bn, p.splits);
   const long stride = M * Cout;
@@ -541,14 +544,12 @@ extern "C" int sfm_aspp_conv3x3_bwd_data(const float* gout, const float* w, int 
   return launch_conv(gout, wt, gin, ws + wsz, B, H, W, Cout, Cin, rate, stream);
 }
 
-// dL/d w [3,3,Cin,Cout].
-extern "C" int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout,
-                                           int rate, float* gw, float* ws, void* stream_) {
-  if (!in || !gout || !gw || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout, rate);
+static int launch_wgrad(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, int rate, float* gw,
+                        float* ws, hipStream_t stream, int ntaps) {
+  if (ntaps == 1) rate = 0;
+  const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout, rate, ntaps);
   float* dst = p.splits > 1 ? ws : gw;
-  const dim3 grid((Cin / p.bm) * (Cout / p.bn), 9, p.splits);
+  const dim3 grid((Cin / p.bm) * (Cout / p.bn), ntaps, p.splits);
   if (p.cfg == 4) {
     const size_t lds = (size_t)(3 * (BK + 2 * rate) * 68 + BK * 36) * sizeof(float);
     hipLaunchKernelGGL(aspp_wgrad9_kernel, dim3((Cin / 64) * (Cout / 32), p.splits), dim3(192), lds, stream, in, gout, dst, B, H,
@@ -566,8 +567,39 @@ extern "C" int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, i
     hipLaunchKernelGGL((aspp_wgrad_kernel<32, 32, 32, 32>), grid, dim3(64), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
                        rate, p.pps);
   if (p.splits > 1) {
-    const long n4 = 9L * Cin * Cout / 4;
+    const long n4 = (long)ntaps * Cin * Cout / 4;
     launch_reduce(ws, n4, p.splits, gw, stream);
   }
   return sfm_last_error();
+}
+
+// dL/d w [3,3,Cin,Cout].
+extern "C" int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout,
+                                           int rate, float* gw, float* ws, void* stream_) {
+  if (!in || !gout || !gw || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
+  return launch_wgrad(in, gout, B, H, W, Cin, Cout, rate, gw, ws, (hipStream_t)stream_, 9);
+}
+
+// ---- 1x1 convolutions of the same block (nets.py:455, 456, 461, 466, 470): slim.conv2d(x, Cout, [1, 1]) itself, NHWC x
+// [1,1,Cin,Cout], as the same implicit-GEMM kernels restricted to the centre tap.  Workspace: the 3x3 one is enough.
+extern "C" int sfm_aspp_conv1x1_fwd(const float* in, const float* w, int B, int H, int W, int Cin, int Cout, float* out,
+                                    float* ws, void* stream) {
+  if (!in || !w || !out || !ws || !conv_dims_ok(B, H, W, Cin, Cout, 1)) return SFM_ERR_ARG;
+  return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, 0, (hipStream_t)stream, 1);
+}
+
+extern "C" int sfm_aspp_conv1x1_bwd_data(const float* gout, const float* w, int B, int H, int W, int Cin, int Cout,
+                                         float* gin, float* ws, void* stream_) {
+  if (!gout || !w || !gin || !ws || !conv_dims_ok(B, H, W, Cin, Cout, 1)) return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* wt = ws;  // [Cout][Cin]
+  hipLaunchKernelGGL(aspp_flip_kernel, dim3(Cin / 32, Cout / 32, 1), dim3(kBlock), 0, stream, w, Cin, Cout, wt);
+  const long wsz = ((long)Cin * Cout + 3) & ~3L;
+  return launch_conv(gout, wt, gin, ws + wsz, B, H, W, Cout, Cin, 0, stream, 1);
+}
+
+extern "C" int sfm_aspp_conv1x1_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout,
+                                           float* gw, float* ws, void* stream) {
+  if (!in || !gout || !gw || !ws || !conv_dims_ok(B, H, W, Cin, Cout, 1)) return SFM_ERR_ARG;
+  return launch_wgrad(in, gout, B, H, W, Cin, Cout, 0, gw, ws, (hipStream_t)stream, 1);
 }

@@ -33,8 +33,8 @@ struct BnPlan {
 static inline bool bn_plan(long M, int C, BnPlan& p) {
   if (M < 1 || C < 4 || C % 4) return false;
   p.groups = C / 4;
-  if (p.groups > kBlock || kBlock % p.groups) return false;
-  p.row_lanes = kBlock / p.groups;
+  if (p.groups > kBlock) return false;
+  p.row_lanes = kBlock / p.groups;  // threads beyond groups * row_lanes idle (C / 4 need not divide 256)
   long chunks = (M + p.row_lanes - 1) / p.row_lanes;  // at least one iteration each
   if (chunks > 512) chunks = 512;
   p.rows_per_chunk = ((M + chunks - 1) / chunks + p.row_lanes - 1) / p.row_lanes * p.row_lanes;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restr
                                                             const float* __restrict__ gy,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, long M, int C, BnPlan p,
-                                                            double* __restrict__ part) {
+                                                            int act, double* __restrict__ part) {
   __shared__ double red[kBlock][8];
   const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
   const long r0 = (long)blockIdx.x * p.rows_per_chunk, r1 = min(M, r0 + p.rows_per_chunk);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restr
     m4 = *reinterpret_cast<const float4*>(mean + 4 * g);
     i4 = *reinterpret_cast<const float4*>(invstd + 4 * g);
   }
-  for (long r = r0 + rl; r < r1; r += p.row_lanes) {
+  for (long r = rl < p.row_lanes ? r0 + rl : r1; r < r1; r += p.row_lanes) {
     const size_t o = (size_t)r * C + 4 * g;
     const float4 xv = *reinterpret_cast<const float4*>(x + o);
     if (MODE == 0) {
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restr
       b[0] += (double)d0 * d0; b[1] += (double)d1 * d1; b[2] += (double)d2 * d2; b[3] += (double)d3 * d3;
     } else {
       const float4 yv = *reinterpret_cast<const float4*>(y + o), gv = *reinterpret_cast<const float4*>(gy + o);
-      const float z0 = gv.x * elu_grad_from_y(yv.x), z1 = gv.y * elu_grad_from_y(yv.y);
-      const float z2 = gv.z * elu_grad_from_y(yv.z), z3 = gv.w * elu_grad_from_y(yv.w);
+      const float z0 = act ? gv.x * elu_grad_from_y(yv.x) : gv.x, z1 = act ? gv.y * elu_grad_from_y(yv.y) : gv.y;
+      const float z2 = act ? gv.z * elu_grad_from_y(yv.z) : gv.z, z3 = act ? gv.w * elu_grad_from_y(yv.w) : gv.w;
       a[0] += z0; a[1] += z1; a[2] += z2; a[3] += z3;
       b[0] += (double)(z0 * ((xv.x - m4.x) * i4.x)); b[1] += (double)(z1 * ((xv.y - m4.y) * i4.y));
       b[2] += (double)(z2 * ((xv.z - m4.z) * i4.z)); b[3] += (double)(z3 * ((xv.w - m4.w) * i4.w));
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void bn_elu_apply_kernel(const float* __res
                                                               const float* __restrict__ beta,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, long n4, int groups,
-                                                              float* __restrict__ y) {
+                                                              int act, float* __restrict__ y) {
   const long e = (long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= n4) return;
   const int g = (int)(e % groups);
@@ -151,10 +151,11 @@ __global__ __launch_bounds__(kBlock) void bn_elu_apply_kernel(const float* __res
   const float4 ga = reinterpret_cast<const float4*>(gamma)[g], be = reinterpret_cast<const float4*>(beta)[g];
   const float4 m = reinterpret_cast<const float4*>(mean)[g], is = reinterpret_cast<const float4*>(invstd)[g];
   float4 o;
-  o.x = elu(ga.x * ((xv.x - m.x) * is.x) + be.x);
-  o.y = elu(ga.y * ((xv.y - m.y) * is.y) + be.y);
-  o.z = elu(ga.z * ((xv.z - m.z) * is.z) + be.z);
-  o.w = elu(ga.w * ((xv.w - m.w) * is.w) + be.w);
+  o.x = ga.x * ((xv.x - m.x) * is.x) + be.x;
+  o.y = ga.y * ((xv.y - m.y) * is.y) + be.y;
+  o.z = ga.z * ((xv.z - m.z) * is.z) + be.z;
+  o.w = ga.w * ((xv.w - m.w) * is.w) + be.w;
+  if (act) { o.x = elu(o.x); o.y = elu(o.y); o.z = elu(o.z); o.w = elu(o.w); }
   reinterpret_cast<float4*>(y)[e] = o;
 }
 
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void bn_elu_bwd_apply_kernel(const float* _
                                                                   const float* __restrict__ invstd,
                                                                   const float* __restrict__ ggamma,
                                                                   const float* __restrict__ gbeta, long n4, int groups,
-                                                                  float inv_m, float* __restrict__ gx) {
+                                                                  float inv_m, int act, float* __restrict__ gx) {
   const long e = (long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= n4) return;
   const int g = (int)(e % groups);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void bn_elu_bwd_apply_kernel(const float* _
   const float4 m = reinterpret_cast<const float4*>(mean)[g], is = reinterpret_cast<const float4*>(invstd)[g];
   const float4 gg = reinterpret_cast<const float4*>(ggamma)[g], gb = reinterpret_cast<const float4*>(gbeta)[g];
   auto one = [&](float xs, float ys, float gs, float gam, float mu, float iv, float dgam, float dbet) {
-    const float dz = gs * elu_grad_from_y(ys);
+    const float dz = act ? gs * elu_grad_from_y(ys) : gs;
     const float xh = (xs - mu) * iv;
     return gam * iv * (dz - dbet * inv_m - xh * (dgam * inv_m));
   };
@@ -200,8 +201,8 @@ extern "C" long long sfm_bn_elu_workspace_floats(long long M, int C) {
 }
 
 extern "C" int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* beta, long long M, int C, float eps, double decay,
-                              float* moving_mean, float* moving_var, float* y, float* save_mean, float* save_invstd,
-                              float* ws, void* stream_) {
+                              int act, float* moving_mean, float* moving_var, float* y, float* save_mean,
+                              float* save_invstd, float* ws, void* stream_) {
   BnPlan p;
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || !bn_plan((long)M, C, p) || !(eps > 0.0f))
     return SFM_ERR_ARG;
@@ -209,18 +210,18 @@ extern "C" int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* b
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks), dim3(kBlock), 0, stream, x, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, part);
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, x, (long)M, C,
                      p.chunks, eps, (float)(1.0 - decay), moving_mean, moving_var, save_mean, save_invstd);
   const long n4 = (long)M * p.groups;
   hipLaunchKernelGGL(bn_elu_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, gamma, beta,
-                     save_mean, save_invstd, n4, p.groups, y);
+                     save_mean, save_invstd, n4, p.groups, act, y);
   return sfm_last_error();
 }
 
 extern "C" int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
-                              const float* save_invstd, long long M, int C, float* gx, float* ggamma, float* gbeta,
-                              float* ws, void* stream_) {
+                              const float* save_invstd, long long M, int C, int act, float* gx, float* ggamma,
+                              float* gbeta, float* ws, void* stream_) {
   BnPlan p;
   if (!x || !y || !gy || !gamma || !save_mean || !save_invstd || !gx || !ggamma || !gbeta || !ws || !bn_plan((long)M, C, p))
     return SFM_ERR_ARG;
@@ -228,11 +229,11 @@ extern "C" int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, c
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
-                     p, part);
+                     p, act, part);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma,
                      gbeta);
   const long n4 = (long)M * p.groups;
   hipLaunchKernelGGL(bn_elu_bwd_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, y, gy,
-                     gamma, save_mean, save_invstd, ggamma, gbeta, n4, p.groups, (float)(1.0 / (double)M), gx);
+                     gamma, save_mean, save_invstd, ggamma, gbeta, n4, p.groups, (float)(1.0 / (double)M), act, gx);
   return sfm_last_error();
 }

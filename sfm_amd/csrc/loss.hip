@@ -35,7 +35,13 @@ constexpr int kCacheTX = 2, kCacheTY = 4, kCacheW = 2 * kCacheTX + 1, kCacheH = 
 // splat: reach of a tile's scan window = ceil(half-range of the tile's displacement) + kReachAdd, clamped.
 // Scanning is cheap (~8 us per 1.0 of redundancy at c2) and a flagged image costs its consumers a second
 // accumulator read, so the reach is generous.
-constexpr int kReachAdd = 4, kReachMin = 6, kReachMax = 16;
+#ifndef SFM_REACH_ADD
+#define SFM_REACH_ADD 4
+#endif
+#ifndef SFM_REACH_MIN
+#define SFM_REACH_MIN 6
+#endif
+constexpr int kReachAdd = SFM_REACH_ADD, kReachMin = SFM_REACH_MIN, kReachMax = 16;
 
 // ------------------------------------------------------------------ fused warp forward
 // The forward splat (utils.py:419-470) without global atomics in the common case.

@@ -322,6 +322,79 @@ __global__ __launch_bounds__(kBlock) void pyramid_upsample_bwd_y_kernel(PyrArgs 
   st_vec<C>(o, acc);
 }
 
+// ------------------------------------------------------------------ the same resize for feature maps (C a multiple of 4)
+// disp_bottleneck_dense upsamples its input x2 (nets.py:454, 465) with up to 1024 channels: one thread per
+// (pixel, group of 4 channels), float4 accesses; the adjoint as the same two separable gather passes.
+struct WideArgs {
+  int B, h, w, G, H, W;  // G = C / 4
+  float sy, sx;
+};
+__device__ __forceinline__ float4 f4_lerp(float4 a, float4 b, float l) {
+  return make_float4(a.x + (b.x - a.x) * l, a.y + (b.y - a.y) * l, a.z + (b.z - a.z) * l, a.w + (b.w - a.w) * l);
+}
+__global__ __launch_bounds__(kBlock) void resize_wide_fwd_kernel(WideArgs a, const float4* __restrict__ in,
+                                                                 float4* __restrict__ out) {
+  const unsigned e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (unsigned)a.B * a.H * a.W * a.G) return;
+  const unsigned pix = e / a.G, g = e - pix * a.G, row = pix / a.W;
+  const int X = (int)(pix - row * a.W), b = (int)(row / a.H), Y = (int)(row - (unsigned)b * a.H);
+  const float4* __restrict__ src = in + (size_t)b * a.h * a.w * a.G + g;
+  if (a.h == a.H && a.w == a.W) { out[e] = src[((size_t)Y * a.w + X) * a.G]; return; }
+  const Lerp ly = lerp_of(Y, a.sy, a.h), lx = lerp_of(X, a.sx, a.w);
+  const float4 tl = src[((size_t)ly.lo * a.w + lx.lo) * a.G], tr = src[((size_t)ly.lo * a.w + lx.hi) * a.G];
+  const float4 bl = src[((size_t)ly.hi * a.w + lx.lo) * a.G], br = src[((size_t)ly.hi * a.w + lx.hi) * a.G];
+  out[e] = f4_lerp(f4_lerp(tl, tr, lx.l), f4_lerp(bl, br, lx.l), ly.l);
+}
+// pass 1: tmp [B,H,w,G]
+__global__ __launch_bounds__(kBlock) void resize_wide_bwd_x_kernel(WideArgs a, const float4* __restrict__ gout,
+                                                                   float4* __restrict__ tmp) {
+  const unsigned e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (unsigned)a.B * a.H * a.w * a.G) return;
+  const unsigned pix = e / a.G, g = e - pix * a.G, row = pix / a.w;  // row = b * H + Y
+  const int x = (int)(pix - row * a.w);
+  const float4* __restrict__ gr = gout + (size_t)row * a.W * a.G + g;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float rx = (float)a.W / (float)a.w;
+  const int X0 = max((int)floorf((float)(x - 1) * rx) - 1, 0), X1 = min((int)ceilf((float)(x + 1) * rx) + 1, a.W - 1);
+  for (int X = X0; X <= X1; ++X) {
+    const Lerp lx = lerp_of(X, a.sx, a.w);
+    if (lx.lo != x && lx.hi != x) continue;
+    const float wx = (lx.lo == x ? 1.0f - lx.l : 0.0f) + (lx.hi == x ? lx.l : 0.0f);
+    const float4 v = gr[(size_t)X * a.G];
+    acc.x += v.x * wx; acc.y += v.y * wx; acc.z += v.z * wx; acc.w += v.w * wx;
+  }
+  tmp[e] = acc;
+}
+__global__ __launch_bounds__(kBlock) void resize_wide_bwd_y_kernel(WideArgs a, const float4* __restrict__ tmp,
+                                                                   float4* __restrict__ gin) {
+  const unsigned e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (unsigned)a.B * a.h * a.w * a.G) return;
+  const unsigned pix = e / a.G, g = e - pix * a.G, row = pix / a.w;
+  const int x = (int)(pix - row * a.w), b = (int)(row / a.h), y = (int)(row - (unsigned)b * a.h);
+  const float4* __restrict__ t = tmp + ((size_t)b * a.H * a.w + x) * a.G + g;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float ry = (float)a.H / (float)a.h;
+  const int Y0 = max((int)floorf((float)(y - 1) * ry) - 1, 0), Y1 = min((int)ceilf((float)(y + 1) * ry) + 1, a.H - 1);
+  for (int Y = Y0; Y <= Y1; ++Y) {
+    const Lerp ly = lerp_of(Y, a.sy, a.h);
+    if (ly.lo != y && ly.hi != y) continue;
+    const float wy = (ly.lo == y ? 1.0f - ly.l : 0.0f) + (ly.hi == y ? ly.l : 0.0f);
+    const float4 v = t[(size_t)Y * a.w * a.G];
+    acc.x += v.x * wy; acc.y += v.y * wy; acc.z += v.z * wy; acc.w += v.w * wy;
+  }
+  gin[e] = acc;
+}
+
+static inline bool small_c(int C) { return C == 1 || C == 2 || C == 3 || C == 4 || C == 6 || C == 9 || C == 12; }
+static int fill_wide(WideArgs& a, int B, int h, int w, int C, int H, int W) {
+  if (B < 1 || h < 1 || w < 1 || H < h || W < w || C < 4 || C % 4) return SFM_ERR_ARG;
+  if ((long)B * H * W * (C / 4) >= 2147483647L) return SFM_ERR_TOO_LARGE;
+  a.B = B; a.h = h; a.w = w; a.G = C / 4; a.H = H; a.W = W;
+  a.sy = (float)h / (float)H;
+  a.sx = (float)w / (float)W;
+  return SFM_OK;
+}
+
 // ------------------------------------------------------------------ smoothness + |t| regulariser
 // compute_smooth_loss (SfMLearner_uni.py:205-219), forward differences:
 //   dx = p[:, :, 1:] - p[:, :, :-1]      dy = p[:, 1:] - p[:, :-1]
@@ -537,12 +610,42 @@ extern "C" int sfm_pyramid_upsample_bwd(const float* gout, const int* h, const i
 }
 
 extern "C" int sfm_resize_bilinear_fwd(const float* in, int B, int h, int w, int C, int H, int W, float* out, void* stream) {
-  return sfm_pyramid_upsample_fwd(&in, &h, &w, 1, B, C, H, W, out, stream);
+  if (small_c(C)) return sfm_pyramid_upsample_fwd(&in, &h, &w, 1, B, C, H, W, out, stream);
+  WideArgs a;
+  const int rc = fill_wide(a, B, h, w, C, H, W);
+  if (rc) return rc;
+  if (!in || !out) return SFM_ERR_ARG;
+  const long n = (long)B * H * W * a.G;
+  hipLaunchKernelGGL(resize_wide_fwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                     reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out));
+  return sfm_last_error();
+}
+
+extern "C" long long sfm_resize_bilinear_bwd_workspace_floats(int B, int h, int w, int C, int H, int W) {
+  if (small_c(C)) return sfm_pyramid_upsample_bwd_workspace_floats(&h, &w, 1, B, C, H, W);
+  WideArgs a;
+  const int rc = fill_wide(a, B, h, w, C, H, W);
+  if (rc) return rc;
+  return (long long)B * H * w * C + 4;
 }
 
 extern "C" int sfm_resize_bilinear_bwd(const float* gout, int B, int h, int w, int C, int H, int W, float* gin, float* ws,
                                        void* stream) {
-  return sfm_pyramid_upsample_bwd(gout, &h, &w, 1, B, C, H, W, 0, &gin, ws, stream);
+  if (small_c(C)) return sfm_pyramid_upsample_bwd(gout, &h, &w, 1, B, C, H, W, 0, &gin, ws, stream);
+  WideArgs a;
+  const int rc = fill_wide(a, B, h, w, C, H, W);
+  if (rc) return rc;
+  if (!gout || !gin || !ws || ((uintptr_t)ws & 15)) return SFM_ERR_ARG;
+  if (h == H && w == W) {
+    const hipError_t e = hipMemcpyAsync(gin, gout, (size_t)B * H * W * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? SFM_OK : (int)e;
+  }
+  const long n1 = (long)B * H * w * a.G, n2 = (long)B * h * w * a.G;
+  hipLaunchKernelGGL(resize_wide_bwd_x_kernel, dim3((unsigned)((n1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     a, reinterpret_cast<const float4*>(gout), reinterpret_cast<float4*>(ws));
+  hipLaunchKernelGGL(resize_wide_bwd_y_kernel, dim3((unsigned)((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     a, reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(gin));
+  return sfm_last_error();
 }
 
 static int fill_norm(NormArgs& a, const float* const* disp, const int* n, int S, int B) {

@@ -94,18 +94,36 @@ def pyramid_upsample_grad(gout: Tensor, sizes: Sequence[Tuple[int, int]],
 class _Resize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out_h, out_w):
-        ctx.size = (x.shape[1], x.shape[2])
-        return pyramid_upsample([x], out_h, out_w)[0]
+        bsz, h, w, ch = x.shape
+        ctx.dims = (bsz, h, w, ch, out_h, out_w)
+        out = torch.empty(bsz, out_h, out_w, ch, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            call("sfm_resize_bilinear_fwd", ptr(x), bsz, h, w, ch, out_h, out_w, ptr(out), stream_of(x))
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        return pyramid_upsample_grad(g.contiguous()[None], [ctx.size])[0], None, None
+        bsz, h, w, ch, out_h, out_w = ctx.dims
+        g = g.contiguous()
+        gin = torch.empty(bsz, h, w, ch, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            ws = torch.empty(_lib.load().sfm_resize_bilinear_bwd_workspace_floats(bsz, h, w, ch, out_h, out_w),
+                             dtype=torch.float32, device=g.device)
+            call("sfm_resize_bilinear_bwd", ptr(g), bsz, h, w, ch, out_h, out_w, ptr(gin), ptr(ws), stream_of(g))
+        return gin, None, None
 
 
 def resize_bilinear(x_nhwc: Tensor, out_h: int, out_w: int) -> Tensor:
     """``tf.image.resize_bilinear(x, [out_h, out_w])`` with TF-1 defaults (align_corners=False, no
-    half-pixel centres; SfMLearner_uni.py:91,113).  Upsampling only, as in the reference."""
-    return _Resize.apply(_check(x_nhwc, "images", 4), int(out_h), int(out_w))
+    half-pixel centres; SfMLearner_uni.py:91,113; nets.py:454,465).  Upsampling only, as in the reference;
+    channels: 1, 2, 3, 4, 6, 9, 12 or any multiple of 4."""
+    x = _check(x_nhwc, "images", 4)
+    ch = x.shape[3]
+    if ch not in SUPPORTED_C and ch % 4:
+        raise ValueError(f"channel count {ch}: must be one of {SUPPORTED_C} or a multiple of 4")
+    if x.shape[1] > out_h or x.shape[2] > out_w:
+        raise ValueError("upsampling only (SfMLearner_uni.py:91,113; nets.py:454): the output must not be smaller")
+    return _Resize.apply(x, int(out_h), int(out_w))
 
 
 # ----------------------------------------------------------------------------- disp normalisation

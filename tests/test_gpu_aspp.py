@@ -140,3 +140,84 @@ def test_batch_norm_elu_rejects_bad_shapes(dev):
         sfm_amd.batch_norm_elu(torch.zeros(1, 2, 2, 6, device=dev), torch.ones(6, device=dev), torch.zeros(6, device=dev))
     with pytest.raises(TypeError):
         sfm_amd.batch_norm_elu(torch.zeros(1, 2, 2, 32), torch.ones(32), torch.zeros(32))
+
+
+# ---------------------------------------------------------------- the rest of disp_bottleneck_dense
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 26, 64, 32), (1, 5, 7, 160, 96), (2, 16, 20, 256, 128), (1, 9, 9, 32, 512)])
+def test_conv1x1(dev, B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(1, 1, Cin, Cout, generator=g) / Cin ** 0.5
+    gy = torch.randn(B, H, W, Cout, generator=g)
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo = R.conv1x1(xo, wo)
+    yo.backward(gy)
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    yg = sfm_amd.conv1x1(xg, wg)
+    yg.backward(gy.to(dev))
+    assert rel_err(yg, yo) <= TOL and rel_err(xg.grad, xo.grad) <= TOL and rel_err(wg.grad, wo.grad) <= TOL
+
+
+@pytest.mark.parametrize("shape,out", [((2, 4, 13, 64), (8, 26)), ((1, 8, 26, 1024), (16, 52)), ((3, 5, 7, 32), (10, 14))])
+def test_resize_feature_maps(dev, shape, out):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(*shape, generator=g)
+    gy = torch.randn(shape[0], out[0], out[1], shape[3], generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = R.resize_bilinear_tf1(xo, *out)
+    yo.backward(gy)
+    xg = x.to(dev).requires_grad_(True)
+    yg = sfm_amd.resize_bilinear(xg, *out)
+    yg.backward(gy.to(dev))
+    assert torch.equal(yg.detach().cpu(), yo.detach())
+    assert rel_err(xg.grad, xo.grad) <= 1e-5
+
+
+def _block_params(g, cin, cout, skip_c, use_skip, use_skip2, skip2_c):
+    def conv(k, ci, co):
+        return dict(w=torch.randn(k, k, ci, co, generator=g) / (k * ci ** 0.5), gamma=torch.rand(co, generator=g) + 0.5,
+                    beta=torch.randn(co, generator=g) * 0.1)
+    p = dict(up=conv(1, cin, cin), sup=conv(1, cin, cout), aspp_up=conv(3, cin, cout), aspp_up2=conv(3, 2 * cout, cout),
+             out=conv(1, (5 if use_skip2 else 4) * cout, cout))
+    if use_skip:
+        p["skip_bn"] = dict(gamma=torch.rand(skip_c, generator=g) + 0.5, beta=torch.randn(skip_c, generator=g) * 0.1)
+        p["skip"] = conv(1, skip_c, cout)
+    else:
+        p["skip"] = conv(3, 2 * cout, cout)
+    if use_skip2:
+        p["skip2"] = conv(1, skip2_c, cout)
+    return p
+
+
+@pytest.mark.parametrize("cin,cout,rates,use_skip,use_skip2", [
+    (128, 64, (2, 4), True, False),    # "concat" / "concat1" form (nets.py:675-676)
+    (64, 32, (3, 6), True, True),      # "concat2" / "concat3" form, with the second skip (:677, 681)
+    (64, 32, (3, 6), False, True),     # "concat4": no skip block, the rate-12 convolution instead (:686, 463)
+])
+def test_disp_bottleneck_dense_block(dev, cin, cout, rates, use_skip, use_skip2):
+    g = torch.Generator().manual_seed(9)
+    B, h, w = 2, 6, 10
+    concat = torch.randn(B, h, w, cin, generator=g)
+    skip_feat = torch.randn(B, 2 * h, 2 * w, 96, generator=g) if use_skip else None
+    skip2 = torch.randn(B, h, w, cin, generator=g) if use_skip2 else None
+    p = _block_params(g, cin, cout, 96, use_skip, use_skip2, cin)
+    # random upstream weights: sum(y^2) of a batch-normalised y is constant up to eps, its gradient pure cancellation
+    wy, wu = torch.randn(B, 2 * h, 2 * w, cout, generator=g), torch.randn(B, 2 * h, 2 * w, cin, generator=g)
+    leaves_o = [concat.clone().requires_grad_(True)] + [q["w"].clone().requires_grad_(True) for q in p.values() if "w" in q]
+    po = {k: dict(v) for k, v in p.items()}
+    for q, wl in zip([q for q in po.values() if "w" in q], leaves_o[1:]):
+        q["w"] = wl
+    yo, uo = R.disp_bottleneck_dense(po, leaves_o[0], skip_feat, rates, use_skip, use_skip2, skip2)
+    ((yo * wy).sum() + (uo * wu).sum()).backward()
+
+    pg = {k: {kk: vv.to(dev) for kk, vv in v.items()} for k, v in p.items()}
+    leaves_g = [concat.to(dev).requires_grad_(True)]
+    for q in [q for q in pg.values() if "w" in q]:
+        q["w"] = q["w"].requires_grad_(True)
+        leaves_g.append(q["w"])
+    yg, ug = sfm_amd.disp_bottleneck_dense(pg, leaves_g[0], None if skip_feat is None else skip_feat.to(dev), rates,
+                                           use_skip, use_skip2, None if skip2 is None else skip2.to(dev))
+    ((yg * wy.to(dev)).sum() + (ug * wu.to(dev)).sum()).backward()
+    assert rel_err(yg, yo) <= 2e-5 and rel_err(ug, uo) <= 2e-5
+    for a, b in zip(leaves_g, leaves_o):
+        assert rel_err(a.grad, b.grad) <= 2e-4
