@@ -234,6 +234,22 @@ int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float*
                    const float* save_invstd, long long M, int C, int act, float* gx, float* ggamma, float* gbeta,
                    float* ws, void* stream);
 
+/* ---- snippet unpack, augmentation and preprocessing (data_loader.py) ---------------
+ * seq: the decoded uint8 snippets [B, H, (n_src+1) W, 3] exactly as tf.image.decode_jpeg returns the files
+ * data/prepare_train_data.py:47 writes (frames side by side), already in device memory; K [B,3,3] from the
+ * <frame>_cam.txt lines (:49-51).  Output: tgt [B,H,W,3] = the centre frame, src [B,H,W,3 n_src] = the frames
+ * before then after it, stacked along the channels (unpack_image_sequence, data_loader.py:296-324), both mapped to
+ * [-1, 1] fp32 (preprocess_image, SfMLearner_uni.py:449-452); K_ms [B,S,3,3] (get_multi_scale_intrinsics,
+ * data_loader.py:348-359).  n_src even, 2 or 4.  augment = 0 is fetch_val_batch (:60-73); augment = 1 is
+ * fetch_train_batch (:126-144) with the random draws made by the caller: x *= brightness (:239-242), x *= col_c
+ * per colour channel (:232-238), uint8 round trip (:272-276), swap != 0 mirrors every frame along the width
+ * (:227-231, intrinsics untouched as in the reference), adjust_contrast by `contrast` about the per-image channel
+ * means (:137), uint8 again.  ws: sfm_snippet_workspace_floats(...) floats, 8-byte aligned (unused if !augment). */
+long long sfm_snippet_workspace_floats(int B, int H, int W, int n_src);
+int sfm_snippet_unpack(const unsigned char* seq, const float* K, int B, int H, int W, int n_src, int S, int augment,
+                       float brightness, float col_r, float col_g, float col_b, int swap, float contrast, float* tgt,
+                       float* src, float* K_ms, float* ws, void* stream);
+
 /* ---- measurement aid (no counterpart in the reference; used by bench.py only) -----------
  * When enabled, sfm_loss_forward / sfm_loss_backward bracket each of their launches with
  * HIP events on the caller's stream; sfm_prof_read adds the last step's elapsed ms per stage

@@ -112,8 +112,29 @@ def pyramid_fixture():
     return out
 
 
+def loader_fixture():
+    """decoded uint8 snippets [B, H, (N+1) W, 3] + intrinsics -> what oracle/ref_loader.py makes of
+    them (validation path and one augmented path with fixed draws), for N = 2 and N = 4."""
+    from oracle import ref_loader as L
+    rng = np.random.default_rng(105)
+    out = {}
+    for tag, (B, H, W, N) in {"n2": (2, 12, 20, 2), "n4": (1, 9, 11, 4)}.items():
+        low = rng.uniform(0, 255, (B, H // 3 + 2, (N + 1) * W // 3 + 2, 3))
+        seq = np.clip(np.kron(low, np.ones((1, 3, 3, 1)))[:, :H, :(N + 1) * W] + rng.uniform(-15, 15, (B, H, (N + 1) * W, 3)),
+                      0, 255).astype(np.uint8)
+        k = np.tile(np.float32([[241.7, 0, 204.2], [0, 246.3, 59.0], [0, 0, 1]]), (B, 1, 1))
+        draws = np.float32([1.17, 0.83, 1.1, 1.19, 1.0, 1.43])  # brightness, colours, swap, contrast
+        vt, vs, km = L.fetch_batch(seq, k, H, W, N, 4, augment=False)
+        at, as_, _ = L.fetch_batch(seq, k, H, W, N, 4, True, float(draws[0]), [float(c) for c in draws[1:4]], bool(draws[4]),
+                                   float(draws[5]))
+        out.update({f"{tag}_dims": np.array([B, H, W, N]), f"{tag}_seq": seq, f"{tag}_K": k, f"{tag}_draws": draws,
+                    f"{tag}_val_tgt": vt, f"{tag}_val_src": vs, f"{tag}_K_ms": km, f"{tag}_aug_tgt": at, f"{tag}_aug_src": as_})
+    return out
+
+
 def main():
     torch.set_num_threads(4)
+    np.savez_compressed(os.path.join(HERE, "loader_snippets.npz"), **loader_fixture())
     np.savez_compressed(os.path.join(HERE, "pyramid_bn_2x16x24.npz"), **pyramid_fixture())
     np.savez_compressed(os.path.join(HERE, "warp_2x16x24.npz"), **warp_fixture(2, 16, 24, 101, 0.05))
     np.savez_compressed(os.path.join(HERE, "warp_3x13x17_oob.npz"), **warp_fixture(3, 13, 17, 102, 0.2))

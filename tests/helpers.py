@@ -71,3 +71,32 @@ def min_select_ambiguous(tgt, src, K, depth_s, pose, trans_s, margin: float = 3e
     rel = ((errs[0] - errs[1]).abs() / torch.maximum(errs[0], errs[1]).clamp_min(1e-30)).amin(dim=3)
     near = ((rel > 0) & (rel < margin)).float()[:, None]  # exact ties (e.g. both warps off-image) are decided alike by every order
     return (torch.nn.functional.max_pool2d(near, 3, 1, 1)[:, 0] > 0)[..., None]
+
+
+def write_snippet_dataset(root, n, H, W, n_src, seed=0, split_val=False):
+    """A dataset directory in the reference's on-disk format (data/prepare_train_data.py:33-51, 99-113): per snippet a
+    jpeg of the n_src+1 frames side by side and '<frame>_cam.txt' = 'fx,0.,cx,0.,fy,cy,0.,0.,1.', plus train.txt /
+    val.txt listing 'folder frame'.  Smooth random content.  Returns (list of uint8 arrays as written, list of K)."""
+    import os
+
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    seqs, cams, lines = [], [], []
+    for i in range(n):
+        folder = "seq_%02d" % (i % 2)
+        os.makedirs(os.path.join(root, folder), exist_ok=True)
+        low = rng.uniform(0, 255, (H // 4 + 2, (n_src + 1) * W // 4 + 2, 3))
+        arr = np.kron(low, np.ones((4, 4, 1)))[:H, :(n_src + 1) * W].astype(np.uint8)
+        Image.fromarray(arr).save(os.path.join(root, folder, "%06d.jpg" % i), quality=95)
+        fx, fy, cx, cy = 241.7 + i, 246.3 + i, 204.2 - i, 59.0 + 0.5 * i
+        with open(os.path.join(root, folder, "%06d_cam.txt" % i), "w") as f:
+            f.write('%f,0.,%f,0.,%f,%f,0.,0.,1.' % (fx, cx, fy, cy))
+        seqs.append(arr)
+        cams.append(np.float32([[fx, 0, cx], [0, fy, cy], [0, 0, 1]]))
+        lines.append("%s %06d\n" % (folder, i))
+    with open(os.path.join(root, "train.txt"), "w") as f:
+        f.writelines(lines)
+    with open(os.path.join(root, "val.txt"), "w") as f:
+        f.writelines(lines[:max(1, n // 2)] if split_val else lines)
+    return seqs, cams
