@@ -393,7 +393,13 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
 // 12-byte d_trans pieces of all sources are stored back to back, so each 128-byte line leaves L2 once).
 // grid: S*B*tiles blocks (1-D).  d_depth [S,B,H,W], d_trans [S,B,H,W,3N], dP partials [S][N*B][tiles][12].
 template <int N>
-__global__ __launch_bounds__(kBlock)
+#ifndef SFM_WPE_BWD
+#define SFM_WPE_BWD
+#endif
+#ifndef SFM_BWD_PAIR
+#define SFM_BWD_PAIR 2  // sources whose gathers are in flight together
+#endif
+__global__ __launch_bounds__(kBlock) SFM_WPE_BWD
 void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                const float* __restrict__ src,
                                                                const float* __restrict__ depth,
@@ -465,8 +471,8 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
     float ddsum = 0.0f;
     float dts[C3];
 #pragma unroll
-    for (int i0 = 0; i0 < N; i0 += 2) {
-      constexpr int kPair = 2;
+    for (int i0 = 0; i0 < N; i0 += SFM_BWD_PAIR) {
+      constexpr int kPair = SFM_BWD_PAIR;
       Geom g[kPair];
       Corners c[kPair];
       int idx[kPair][4];

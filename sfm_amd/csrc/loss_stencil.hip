@@ -25,6 +25,14 @@
 #include "loss_common.h"
 #include <type_traits>
 
+// occupancy targets (waves per SIMD): see the Makefile / DESIGN.md section 5
+#ifndef SFM_WPE_GATHER
+#define SFM_WPE_GATHER
+#endif
+#ifndef SFM_WPE_SPLAT
+#define SFM_WPE_SPLAT
+#endif
+
 namespace sfm {
 
 namespace {
@@ -37,14 +45,65 @@ namespace {
 constexpr float kG0 = 0.38439732789993286f;
 constexpr float kG1 = 0.30780133605003357f;
 
-__device__ __forceinline__ float lane_left(float v) {  // lane i <- lane i-1 (0 into lane 0)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+// ---- horizontal 3-tap sums across the lanes of a wave --------------------------------------------------------
+// out[k] = g0 in[k] + g1 (in[k] of lane-1 + in[k] of lane+1), 0 beyond the ends of the wave.  Written as ONE asm
+// statement per group of values: N plain multiplies, then 2N v_fmac_f32_dpp (the DPP operand folded into the FMA: 3
+// instructions per sum where the compiler's v_mov_dpp / v_add_dpp / mul / fmac form took 5 plus hazard s_nops, and DPP
+// forms issue at half rate - tools/valu_bench.hip).  gfx950 wants 2 wait states between the VALU write of a register
+// and a DPP read of it: the N >= 3 leading multiplies are those wait states for anything written just before the
+// statement, and inside it the DPP operands are inputs only.  The taps live in VGPRs (DPP encodings take no literal).
+#define SFM_DPP_L " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"  // lane i <- lane i-1
+#define SFM_DPP_R " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"  // lane i <- lane i+1
+#define HS_M(o, i) "v_mul_f32 %" #o ", %[g0], %" #i "\n"
+#define HS_L(o, i) "v_fmac_f32_dpp %" #o ", %" #i ", %[g1]" SFM_DPP_L
+#define HS_R(o, i) "v_fmac_f32_dpp %" #o ", %" #i ", %[g1]" SFM_DPP_R
+struct Taps {
+  float g0, g1;
+};
+__device__ __forceinline__ void hsum3(const float (&in)[3], float (&o)[3], const Taps t) {
+  asm(HS_M(0, 3) HS_M(1, 4) HS_M(2, 5) HS_L(0, 3) HS_L(1, 4) HS_L(2, 5) HS_R(0, 3) HS_R(1, 4) HS_R(2, 5)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), [g0] "v"(t.g0), [g1] "v"(t.g1));
 }
-__device__ __forceinline__ float lane_right(float v) {  // lane i <- lane i+1 (0 into lane 63)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+__device__ __forceinline__ void hsum3(const float (&in)[4], float (&o)[4], const Taps t) {
+  asm(HS_M(0, 4) HS_M(1, 5) HS_M(2, 6) HS_M(3, 7) HS_L(0, 4) HS_L(1, 5) HS_L(2, 6) HS_L(3, 7) HS_R(0, 4) HS_R(1, 5)
+          HS_R(2, 6) HS_R(3, 7)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]), [g0] "v"(t.g0), [g1] "v"(t.g1));
 }
-__device__ __forceinline__ float hsum3(float v) { return kG0 * v + kG1 * (lane_left(v) + lane_right(v)); }
-__device__ __forceinline__ float vsum3(float top, float mid, float bot) { return kG0 * mid + kG1 * (top + bot); }
+__device__ __forceinline__ void hsum3(const float (&in)[6], float (&o)[6], const Taps t) {
+  asm(HS_M(0, 6) HS_M(1, 7) HS_M(2, 8) HS_M(3, 9) HS_M(4, 10) HS_M(5, 11) HS_L(0, 6) HS_L(1, 7) HS_L(2, 8) HS_L(3, 9)
+          HS_L(4, 10) HS_L(5, 11) HS_R(0, 6) HS_R(1, 7) HS_R(2, 8) HS_R(3, 9) HS_R(4, 10) HS_R(5, 11)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]), "v"(in[4]), "v"(in[5]), [g0] "v"(t.g0), [g1] "v"(t.g1));
+}
+__device__ __forceinline__ void hsum3(const float (&in)[7], float (&o)[7], const Taps t) {
+  asm(HS_M(0, 7) HS_M(1, 8) HS_M(2, 9) HS_M(3, 10) HS_M(4, 11) HS_M(5, 12) HS_M(6, 13) HS_L(0, 7) HS_L(1, 8) HS_L(2, 9)
+          HS_L(3, 10) HS_L(4, 11) HS_L(5, 12) HS_L(6, 13) HS_R(0, 7) HS_R(1, 8) HS_R(2, 9) HS_R(3, 10) HS_R(4, 11)
+              HS_R(5, 12) HS_R(6, 13)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]), "v"(in[4]), "v"(in[5]), "v"(in[6]), [g0] "v"(t.g0),
+        [g1] "v"(t.g1));
+}
+// unweighted: o[k] = in[k] + its two lane neighbours (the 3-tap half of avg_pool 3x3)
+__device__ __forceinline__ void nsum3(const float (&in)[3], float (&o)[3]) {
+  asm("v_mov_b32 %0, %3\nv_mov_b32 %1, %4\nv_mov_b32 %2, %5\n"
+      "v_add_f32_dpp %0, %3, %0" SFM_DPP_L "v_add_f32_dpp %1, %4, %1" SFM_DPP_L "v_add_f32_dpp %2, %5, %2" SFM_DPP_L
+      "v_add_f32_dpp %0, %3, %0" SFM_DPP_R "v_add_f32_dpp %1, %4, %1" SFM_DPP_R "v_add_f32_dpp %2, %5, %2" SFM_DPP_R
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]));
+}
+// ---- vertical 3-tap sums in scatter form ------------------------------------------------------------------------
+// A row's horizontal sum h is pushed into two running accumulators per quantity (p1: the window centred on the previous
+// row, complete after this push; p0: the window centred on this row) instead of being kept in a 3-row ring: the state
+// carried from row to row is 2 registers per quantity instead of 3, which is what lets another wave fit on the SIMD.
+// Returns the completed sum g1 h[r-2] + g0 h[r-1] + g1 h[r] for row r-1.
+__device__ __forceinline__ float vpush(float& p1, float& p0, float h) {
+  const float out = __builtin_fmaf(kG1, h, p1);
+  p1 = __builtin_fmaf(kG0, h, p0);
+  p0 = kG1 * h;
+  return out;
+}
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 
 __device__ __forceinline__ float clip01_half(float v) {  // clip((1 - v)/2, 0, 1), utils.py:575
@@ -96,122 +155,97 @@ __device__ __forceinline__ Item split_item(long item, const StencilPlan& p) {
   return it;
 }
 
-__device__ __forceinline__ float rows_in(int q, int H) {  // in-bounds taps of a 3-tap window at q
-  return (float)(min(q + 1, H - 1) - max(q - 1, 0) + 1);
-}
 
 // ------------------------------------------------------------------ splat side
 // x = Sp_i = Acc.rgb / (Acc.w + 1e-10) (utils.py:463,470), y = src_i.  Sums A = sum m |x - y|,
 // M = sum m, V = sum ssim(x, y) with m = avgpool3x3_SAME(1 - [x == 0]) (utils.py:478-479).
 //
-// Register windows are 3-slot rings indexed by (row mod 3); the row loop is unrolled by 3 with the
-// phase as a compile-time constant, so sliding a window is a renaming, not a move.
+// Per step (image row r): the row's values and their horizontal sums are pushed into the vertical accumulators, which
+// completes the windowed moments of row q = r - 1 -> SSIM value, mask, sums and derivative coefficients of row q; the
+// coefficients' horizontal sums are pushed in turn, which completes the transposed window of row p = r - 2 -> seeds.
+// The raw values of the last three rows sit in 3-slot rings indexed by (row mod 3); the row loop is unrolled by 3 with
+// the phase as a compile-time constant, so sliding a ring is a renaming, not a move.
+// The wave's constants and running state live in a struct with force-inlined member functions (not in lambdas
+// capturing by reference: with the closure form the compiler inlined the bodies only after its last scalar-replacement
+// pass and left every captured local - all the state below - in scratch memory, 7x slower).
 template <bool GRAD>
-__device__ __forceinline__ void splat_item(const StencilArgs& a, long item, float* __restrict__ wavep_out) {
-  const LossDims d = a.d;
-  const Item it = split_item(item, a.p);
-  const int lane = threadIdx.x & 63;
-  const int b = it.img % d.B, i = (it.img / d.B) % d.N;
-  const int HW = d.H * d.W, C3 = 3 * d.N;
-  const int gx = it.strip * kStripOwn - 2 + lane;
-  const bool col_in = gx >= 0 && gx < d.W;
-  const bool own_col = lane >= 2 && lane < 62 && gx < d.W;
-  const int y0 = it.chunk * a.p.rows, y1 = min(y0 + a.p.rows, d.H);
-  const float* __restrict__ acc = a.Acc + (size_t)it.img * HW * 4;
-  const float* __restrict__ ovf = a.flags[it.img] ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;  // wave-uniform
-  const float* __restrict__ sp = a.src + (size_t)b * HW * C3 + 3 * i;
-  float* __restrict__ hb = a.Hb + (size_t)it.img * HW * 4;  // part A; part B one plane further
-  const size_t hb_plane = (size_t)d.S * d.N * d.B * HW * 4;
-  const float nx = (float)(min(gx + 1, d.W - 1) - max(gx - 1, 0) + 1);
-  constexpr int HAL = GRAD ? 2 : 1;
-  const int r_first = y0 - HAL, r_last = y1 - 1 + HAL;
+struct SplatWave {
+  LossDims d;
+  int gx, y0, y1, r_first, r_last;
+  bool col_in, own_col;
+  const float* __restrict__ acc;
+  const float* __restrict__ ovf;
+  const float* __restrict__ sp;
+  float* __restrict__ hb;
+  size_t hb_plane;
+  int C3;
+  float kL1;
+  Taps taps;
+  float P1[3][4], P0[3][4];  // vertical accumulators of the moments x, y, xx + yy, xy per channel
+  float N1[3], N0[3];        // ... of the non-zero counts
+  float C1[3][3], C0[3][3];  // ... of the derivative coefficients (a, b, c)
+  float X[3][3], Y[3][3], Iv[3], Mk[3][3];  // rings, slot = (row - r_first) mod 3
+  float sA, sM, sV;
+  float na[4], ns[3];  // software prefetch of the next row's raw values (plain floats: a float4 member is assigned by
+                       // memcpy, which kept the whole struct in scratch)
 
-  // rings, slot = (row - r_first) mod 3.  moments per channel: x, y, xx + yy, xy
-  float Hm[3][3][4], Nz[3][3], Ch[3][3][3], X[3][3], Y[3][3], Iv[3], Mk[3][3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    Iv[k] = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      Nz[k][ch] = X[k][ch] = Y[k][ch] = Mk[k][ch] = 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) Hm[k][ch][m] = 0.f;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) Ch[k][ch][m] = 0.f;
-    }
-  }
-  float sA = 0.f, sM = 0.f, sV = 0.f;
-
-  float4 na = make_float4(0.f, 0.f, 0.f, 0.f);  // software prefetch of the next row's raw values
-  f3 ns{0.f, 0.f, 0.f};
-  auto fetch = [&](int r) {
-    na = make_float4(0.f, 0.f, 0.f, 0.f);
-    ns = f3{0.f, 0.f, 0.f};
+  __device__ __forceinline__ void fetch(int r) {
+    na[0] = na[1] = na[2] = na[3] = 0.f;
+    ns[0] = ns[1] = ns[2] = 0.f;
     if (r >= 0 && r < d.H && col_in) {
       const size_t p = (size_t)r * d.W + gx;
-      na = *reinterpret_cast<const float4*>(acc + p * 4);
+      const float4 t = *reinterpret_cast<const float4*>(acc + p * 4);
+      na[0] = t.x; na[1] = t.y; na[2] = t.z; na[3] = t.w;
       if (ovf) {
         const float4 o = *reinterpret_cast<const float4*>(ovf + p * 4);
-        na.x += o.x; na.y += o.y; na.z += o.z; na.w += o.w;
+        na[0] += o.x; na[1] += o.y; na[2] += o.z; na[3] += o.w;
       }
-      ns = ld3(sp + p * C3);
+      const f3 u = ld3(sp + p * C3);
+      ns[0] = u.x; ns[1] = u.y; ns[2] = u.z;
     }
-  };
+  }
 
-  auto step = [&](int r, auto ph) {
-    constexpr int S0 = decltype(ph)::value;            // slot of row r
-    constexpr int S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;  // slots of rows r-1, r-2 (r-3 shares S0)
-    const float4 ca = na;
-    const f3 cs = ns;
+  // S0: ring slot of row r.  rc3 / rc2 / rc1 = 1 / (taps of the 3x3 SAME window inside the image) for 3, 2, 1 rows in
+  // bounds: by value - a select between struct MEMBERS becomes a select between their addresses, which keeps the whole
+  // struct (all the wave's state) in scratch memory
+  template <int S0>
+  __device__ __forceinline__ void step(int r, float rc3, float rc2, float rc1) {
+    constexpr int S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;  // slots of rows r-1, r-2
+    const float ca[4] = {na[0], na[1], na[2], na[3]}, yv[3] = {ns[0], ns[1], ns[2]};
     if (r + 1 <= r_last) fetch(r + 1);
-    // ---- row r: values, horizontal sums
-    if (r >= 0 && r < d.H) {  // wave-uniform
-      const float inv = col_in ? fast_rcp(ca.w + 1e-10f) : 0.f;
-      Iv[S0] = inv;
-      const float xv[3] = {ca.x * inv, ca.y * inv, ca.z * inv}, yv[3] = {cs.x, cs.y, cs.z};  // 0 outside the image
-      // all products first, then all cross-lane sums: a DPP operand needs two wait states after the VALU write of
-      // its source, and the compiler pads with s_nop when the product is formed right in front of its hsum3
-      float sq[3], xy[3], nz[3];
+    // ---- row r: values (0 outside the image: the prefetch loaded nothing), horizontal sums, vertical push
+    const float inv = (col_in && r >= 0 && r < d.H) ? fast_rcp(ca[3] + 1e-10f) : 0.f;
+    Iv[S0] = inv;
+    const float xv[3] = {ca[0] * inv, ca[1] * inv, ca[2] * inv};
+    float mom[3][4], nz[3], nzh[3];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        X[S0][ch] = xv[ch];
-        Y[S0][ch] = yv[ch];
-        sq[ch] = xv[ch] * xv[ch] + yv[ch] * yv[ch];
-        xy[ch] = xv[ch] * yv[ch];
-        nz[ch] = (xv[ch] == 0.0f) ? 0.0f : 1.0f;
-      }
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        Hm[S0][ch][0] = hsum3(xv[ch]);
-        Hm[S0][ch][1] = hsum3(yv[ch]);
-        Hm[S0][ch][2] = hsum3(sq[ch]);
-        Hm[S0][ch][3] = hsum3(xy[ch]);
-        Nz[S0][ch] = nz[ch] + (lane_left(nz[ch]) + lane_right(nz[ch]));
-      }
-    } else {
-      Iv[S0] = 0.f;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        X[S0][ch] = Y[S0][ch] = Nz[S0][ch] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) Hm[S0][ch][m] = 0.f;
-      }
+    for (int ch = 0; ch < 3; ++ch) {
+      X[S0][ch] = xv[ch];
+      Y[S0][ch] = yv[ch];
+      nz[ch] = (xv[ch] == 0.0f) ? 0.0f : 1.0f;
     }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float in4[4] = {xv[ch], yv[ch], xv[ch] * xv[ch] + yv[ch] * yv[ch], xv[ch] * yv[ch]};
+      float h4[4];
+      hsum3(in4, h4, taps);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mom[ch][m] = vpush(P1[ch][m], P0[ch][m], h4[m]);
+    }
+    nsum3(nz, nzh);
     // ---- row q = r - 1: windowed moments -> SSIM value, derivative coefficients, mask, sums
     const int q = r - 1;
     if (r - r_first >= 2) {
       const bool pix_in = q >= 0 && q < d.H && col_in;
       const bool own = own_col && q >= y0 && q < y1;
-      const float rcnt = 1.0f / (rows_in(q, d.H) * nx);  // k * fl(1/k) == 1 exactly for k = 4, 6, 9
-      float cf[3][3];
+      const int rin = min(q + 1, d.H - 1) - max(q - 1, 0) + 1;
+      const float rcnt = rin == 3 ? rc3 : (rin == 2 ? rc2 : rc1);
+      float cf[3][3], hc[3][3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         float ca_ = 0.f, cb_ = 0.f, cc_ = 0.f;
-        const float v = ssim_point<GRAD>(vsum3(Hm[S2][ch][0], Hm[S1][ch][0], Hm[S0][ch][0]),
-                                         vsum3(Hm[S2][ch][1], Hm[S1][ch][1], Hm[S0][ch][1]),
-                                         vsum3(Hm[S2][ch][2], Hm[S1][ch][2], Hm[S0][ch][2]),
-                                         vsum3(Hm[S2][ch][3], Hm[S1][ch][3], Hm[S0][ch][3]), ca_, cb_, cc_);
-        const float m = ((Nz[S2][ch] + Nz[S1][ch]) + Nz[S0][ch]) * rcnt;
+        const float v = ssim_point<GRAD>(mom[ch][0], mom[ch][1], mom[ch][2], mom[ch][3], ca_, cb_, cc_);
+        const float m = (N1[ch] + nzh[ch]) * rcnt;
         Mk[S1][ch] = m;
         if (own) {
           sV += v;
@@ -224,43 +258,92 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
           cf[ch][2] = pix_in ? cc_ : 0.f;
         }
       }
-      if constexpr (GRAD) {  // coefficients of row q overwrite those of row q - 3 (same slot); sums after all values (DPP hazard)
+      // ---- row p = r - 2: the transposed window of the coefficients -> backward seeds
+      if constexpr (GRAD) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) hsum3(cf[ch], hc[ch], taps);
+        float rr[3][3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-          for (int m = 0; m < 3; ++m) Ch[S1][ch][m] = hsum3(cf[ch][m]);
-      }
-    }
-    // ---- row p = r - 2: backward seeds (coefficient rows p-1, p, p+1 sit in slots S0, S2, S1)
-    if constexpr (GRAD) {
-      const int p = r - 2;
-      if (own_col && p >= y0 && p < y1) {
-        float hA[3], hB[3], wA = 0.f, wB = 0.f;
+          for (int m = 0; m < 3; ++m) rr[ch][m] = vpush(C1[ch][m], C0[ch][m], hc[ch][m]);
+        const int p = r - 2;
+        if (own_col && p >= y0 && p < y1) {
+          float hA[3], hB[3], wA = 0.f, wB = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float xv = X[S2][ch], yv = Y[S2][ch];
-          const float rr = vsum3(Ch[S0][ch][0], Ch[S2][ch][0], Ch[S1][ch][0]) +
-                           2.0f * vsum3(Ch[S0][ch][1], Ch[S2][ch][1], Ch[S1][ch][1]) * xv +
-                           vsum3(Ch[S0][ch][2], Ch[S2][ch][2], Ch[S1][ch][2]) * yv;
-          hA[ch] = (a.kL1 * Mk[S2][ch] * sgn(xv - yv)) * Iv[S2];
-          hB[ch] = rr * Iv[S2];
-          wA += hA[ch] * xv;
-          wB += hB[ch] * xv;
+          for (int ch = 0; ch < 3; ++ch) {
+            const float xq = X[S2][ch], yq = Y[S2][ch];
+            const float g = rr[ch][0] + 2.0f * rr[ch][1] * xq + rr[ch][2] * yq;
+            hA[ch] = (kL1 * Mk[S2][ch] * sgn(xq - yq)) * Iv[S2];
+            hB[ch] = g * Iv[S2];
+            wA += hA[ch] * xq;
+            wB += hB[ch] * xq;
+          }
+          float* o = hb + ((size_t)p * d.W + gx) * 4;
+          *reinterpret_cast<float4*>(o) = make_float4(hA[0], hA[1], hA[2], wA);
+          *reinterpret_cast<float4*>(o + hb_plane) = make_float4(hB[0], hB[1], hB[2], wB);
         }
-        float* o = hb + ((size_t)p * d.W + gx) * 4;
-        *reinterpret_cast<float4*>(o) = make_float4(hA[0], hA[1], hA[2], wA);
-        *reinterpret_cast<float4*>(o + hb_plane) = make_float4(hB[0], hB[1], hB[2], wB);
       }
     }
-  };
-
-  fetch(r_first);
-  for (int r = r_first; r <= r_last; r += 3) {
-    step(r, IC<0>{});
-    if (r + 1 <= r_last) step(r + 1, IC<1>{});
-    if (r + 2 <= r_last) step(r + 2, IC<2>{});
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {  // slide the count window
+      N1[ch] = N0[ch] + nzh[ch];
+      N0[ch] = nzh[ch];
+    }
   }
-  sA = wave_sum_dpp_lane63(sA); sM = wave_sum_dpp_lane63(sM); sV = wave_sum_dpp_lane63(sV);
+};
+
+template <bool GRAD>
+__device__ __forceinline__ void splat_item(const StencilArgs& a, long item, float* __restrict__ wavep_out) {
+  SplatWave<GRAD> w;
+  const LossDims d = a.d;
+  w.d = d;
+  const Item it = split_item(item, a.p);
+  const int lane = threadIdx.x & 63;
+  const int b = it.img % d.B, i = (it.img / d.B) % d.N;
+  const int HW = d.H * d.W;
+  w.C3 = 3 * d.N;
+  w.gx = it.strip * kStripOwn - 2 + lane;
+  w.col_in = w.gx >= 0 && w.gx < d.W;
+  w.own_col = lane >= 2 && lane < 62 && w.gx < d.W;
+  w.y0 = it.chunk * a.p.rows;
+  w.y1 = min(w.y0 + a.p.rows, d.H);
+  w.acc = a.Acc + (size_t)it.img * HW * 4;
+  w.ovf = a.flags[it.img] ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;  // wave-uniform
+  w.sp = a.src + (size_t)b * HW * w.C3 + 3 * i;
+  w.hb = a.Hb + (size_t)it.img * HW * 4;  // part A; part B one plane further
+  w.hb_plane = (size_t)d.S * d.N * d.B * HW * 4;
+  const float nx = (float)(min(w.gx + 1, d.W - 1) - max(w.gx - 1, 0) + 1);
+  // 1 / (taps of the 3x3 SAME window inside the image): k * fl(1/k) == 1 exactly for k = 4, 6, 9
+  const float rc3 = 1.0f / (3.0f * nx), rc2 = 1.0f / (2.0f * nx), rc1 = 1.0f / nx;
+  w.kL1 = a.kL1;
+  w.taps = Taps{kG0, kG1};
+  constexpr int HAL = GRAD ? 2 : 1;
+  w.r_first = w.y0 - HAL;
+  w.r_last = w.y1 - 1 + HAL;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    w.N1[ch] = w.N0[ch] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) w.P1[ch][m] = w.P0[ch][m] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) w.C1[ch][m] = w.C0[ch][m] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    w.Iv[k] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) w.X[k][ch] = w.Y[k][ch] = w.Mk[k][ch] = 0.f;
+  }
+  w.sA = w.sM = w.sV = 0.f;
+
+  w.fetch(w.r_first);
+  for (int r = w.r_first; r <= w.r_last; r += 3) {
+    w.template step<0>(r, rc3, rc2, rc1);
+    if (r + 1 <= w.r_last) w.template step<1>(r + 1, rc3, rc2, rc1);
+    if (r + 2 <= w.r_last) w.template step<2>(r + 2, rc3, rc2, rc1);
+  }
+  const float sA = wave_sum_dpp_lane63(w.sA), sM = wave_sum_dpp_lane63(w.sM), sV = wave_sum_dpp_lane63(w.sV);
   if (lane == 63) *reinterpret_cast<float4*>(wavep_out) = make_float4(sA, sM, sV, 0.f);
 }
 
@@ -288,25 +371,24 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
   const int r_first = y0 - HAL, r_last = y1 - 1 + HAL;
   const float ku = a.kE * (1.0f - kAlpha) * (-0.5f);
   const float kl = a.kE * kAlpha;
+  const Taps taps{kG0, kG1};
 
-  // rings, slot = (row - r_first) mod 3.  moments per channel: t, x0, x1, x0x0 + tt, x1x1 + tt, x0t, x1t
-  float Hm[3][3][7];
-  float Ch[3][3][6];  // (a0, b0, c0, a1, b1, c1), already scaled by the selection
-  float X0[3][3], X1[3][3], T[3][3], Sel[3][3];
+  float P1[3][7], P0[3][7];  // vertical accumulators of the moments t, x0, x1, x0x0 + tt, x1x1 + tt, x0t, x1t per channel
+  float C1[3][6], C0[3][6];  // ... of the coefficients (a0, b0, c0, a1, b1, c1), already scaled by the selection
+  float X0[3][3], X1[3][3], T[3][3], Sel[3][3];  // rings, slot = (row - r_first) mod 3
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+  for (int ch = 0; ch < 3; ++ch) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      X0[k][ch] = X1[k][ch] = T[k][ch] = Sel[k][ch] = 0.f;
+    for (int m = 0; m < 7; ++m) P1[ch][m] = P0[ch][m] = 0.f;
 #pragma unroll
-      for (int m = 0; m < 7; ++m) Hm[k][ch][m] = 0.f;
+    for (int m = 0; m < 6; ++m) C1[ch][m] = C0[ch][m] = 0.f;
 #pragma unroll
-      for (int m = 0; m < 6; ++m) Ch[k][ch][m] = 0.f;
-    }
+    for (int k = 0; k < 3; ++k) X0[k][ch] = X1[k][ch] = T[k][ch] = Sel[k][ch] = 0.f;
+  }
   float sE = 0.f;
 
   f3 n0{0.f, 0.f, 0.f}, n1{0.f, 0.f, 0.f}, nt{0.f, 0.f, 0.f};
-  auto fetch = [&](int r) {
+  auto fetch = [&](int r) __attribute__((always_inline)) {
     n0 = n1 = nt = f3{0.f, 0.f, 0.f};
     if (r >= 0 && r < d.H && col_in) {
       const size_t p = ((size_t)r * d.W + gx) * 3;
@@ -316,39 +398,21 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
     }
   };
 
-  auto step = [&](int r, auto ph) {
+  auto step = [&](int r, auto ph) __attribute__((always_inline)) {
     constexpr int S0 = decltype(ph)::value;
     constexpr int S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;
-    const float x0[3] = {n0.x, n0.y, n0.z}, x1[3] = {n1.x, n1.y, n1.z}, t[3] = {nt.x, nt.y, nt.z};
+    const float x0[3] = {n0.x, n0.y, n0.z}, x1[3] = {n1.x, n1.y, n1.z}, t[3] = {nt.x, nt.y, nt.z};  // 0 outside the image
     if (r + 1 <= r_last) fetch(r + 1);
-    if (r >= 0 && r < d.H) {
-      float pr[3][4];  // products first, cross-lane sums after (DPP hazard: see splat_item)
+    float mm[3][7];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        X0[S0][ch] = x0[ch]; X1[S0][ch] = x1[ch]; T[S0][ch] = t[ch];
-        const float tt = t[ch] * t[ch];
-        pr[ch][0] = x0[ch] * x0[ch] + tt;
-        pr[ch][1] = x1[ch] * x1[ch] + tt;
-        pr[ch][2] = x0[ch] * t[ch];
-        pr[ch][3] = x1[ch] * t[ch];
-      }
+    for (int ch = 0; ch < 3; ++ch) {
+      X0[S0][ch] = x0[ch]; X1[S0][ch] = x1[ch]; T[S0][ch] = t[ch];
+      const float tt = t[ch] * t[ch];
+      const float in7[7] = {t[ch], x0[ch], x1[ch], x0[ch] * x0[ch] + tt, x1[ch] * x1[ch] + tt, x0[ch] * t[ch], x1[ch] * t[ch]};
+      float h7[7];
+      hsum3(in7, h7, taps);
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        Hm[S0][ch][0] = hsum3(t[ch]);
-        Hm[S0][ch][1] = hsum3(x0[ch]);
-        Hm[S0][ch][2] = hsum3(x1[ch]);
-        Hm[S0][ch][3] = hsum3(pr[ch][0]);
-        Hm[S0][ch][4] = hsum3(pr[ch][1]);
-        Hm[S0][ch][5] = hsum3(pr[ch][2]);
-        Hm[S0][ch][6] = hsum3(pr[ch][3]);
-      }
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        X0[S0][ch] = X1[S0][ch] = T[S0][ch] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 7; ++m) Hm[S0][ch][m] = 0.f;
-      }
+      for (int m = 0; m < 7; ++m) mm[ch][m] = vpush(P1[ch][m], P0[ch][m], h7[m]);
     }
     const int q = r - 1;
     if (r - r_first >= 2) {
@@ -357,12 +421,9 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
       float cf[3][6];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        float mm[7];
-#pragma unroll
-        for (int m = 0; m < 7; ++m) mm[m] = vsum3(Hm[S2][ch][m], Hm[S1][ch][m], Hm[S0][ch][m]);
         float a0 = 0.f, b0 = 0.f, c0 = 0.f, a1 = 0.f, b1 = 0.f, c1 = 0.f;
-        const float v0 = ssim_point<GRAD>(mm[1], mm[0], mm[3], mm[5], a0, b0, c0);
-        const float v1 = ssim_point<GRAD>(mm[2], mm[0], mm[4], mm[6], a1, b1, c1);
+        const float v0 = ssim_point<GRAD>(mm[ch][1], mm[ch][0], mm[ch][3], mm[ch][5], a0, b0, c0);
+        const float v1 = ssim_point<GRAD>(mm[ch][2], mm[ch][0], mm[ch][4], mm[ch][6], a1, b1, c1);
         const float e0 = kAlpha * fabsf(X0[S1][ch] - T[S1][ch]) + (1.0f - kAlpha) * clip01_half(v0);
         const float e1 = kAlpha * fabsf(X1[S1][ch] - T[S1][ch]) + (1.0f - kAlpha) * clip01_half(v1);
         const bool first = e0 <= e1;  // tf.minimum ties -> either (equal values)
@@ -376,29 +437,27 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
         }
       }
       if constexpr (GRAD) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-          for (int m = 0; m < 6; ++m) Ch[S1][ch][m] = hsum3(cf[ch][m]);
-      }
-    }
-    if constexpr (GRAD) {
-      const int p = r - 2;
-      if (own_col && p >= y0 && p < y1) {
-        float d0[3], d1[3];
+        float rr[3][6];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float tv = T[S2][ch], xa = X0[S2][ch], xb = X1[S2][ch];
-          d0[ch] = kl * Sel[S2][ch] * sgn(xa - tv) +
-                   (vsum3(Ch[S0][ch][0], Ch[S2][ch][0], Ch[S1][ch][0]) + 2.0f * vsum3(Ch[S0][ch][1], Ch[S2][ch][1], Ch[S1][ch][1]) * xa +
-                    vsum3(Ch[S0][ch][2], Ch[S2][ch][2], Ch[S1][ch][2]) * tv);
-          d1[ch] = kl * (1.0f - Sel[S2][ch]) * sgn(xb - tv) +
-                   (vsum3(Ch[S0][ch][3], Ch[S2][ch][3], Ch[S1][ch][3]) + 2.0f * vsum3(Ch[S0][ch][4], Ch[S2][ch][4], Ch[S1][ch][4]) * xb +
-                    vsum3(Ch[S0][ch][5], Ch[S2][ch][5], Ch[S1][ch][5]) * tv);
+          float hc[6];
+          hsum3(cf[ch], hc, taps);
+#pragma unroll
+          for (int m = 0; m < 6; ++m) rr[ch][m] = vpush(C1[ch][m], C0[ch][m], hc[m]);
         }
-        const size_t pp = ((size_t)p * d.W + gx) * 3;
-        st3(a.dG + o0 + pp, d0[0], d0[1], d0[2]);
-        st3(a.dG + o1 + pp, d1[0], d1[1], d1[2]);
+        const int p = r - 2;
+        if (own_col && p >= y0 && p < y1) {
+          float d0[3], d1[3];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float tv = T[S2][ch], xa = X0[S2][ch], xb = X1[S2][ch];
+            d0[ch] = kl * Sel[S2][ch] * sgn(xa - tv) + (rr[ch][0] + 2.0f * rr[ch][1] * xa + rr[ch][2] * tv);
+            d1[ch] = kl * (1.0f - Sel[S2][ch]) * sgn(xb - tv) + (rr[ch][3] + 2.0f * rr[ch][4] * xb + rr[ch][5] * tv);
+          }
+          const size_t pp = ((size_t)p * d.W + gx) * 3;
+          st3(a.dG + o0 + pp, d0[0], d0[1], d0[2]);
+          st3(a.dG + o1 + pp, d1[0], d1[1], d1[2]);
+        }
       }
     }
   };
@@ -417,12 +476,12 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
 // XCD-contiguous order measured 25 % MORE fetched bytes here - profiles/r01_traffic.md).  Two kernels because the register
 // budgets differ (the gather side carries two SSIMs per channel).
 template <bool GRAD>
-__global__ __launch_bounds__(kBlock) void loss_stencil_gather_kernel(StencilArgs a) {
+__global__ __launch_bounds__(kBlock) SFM_WPE_GATHER void loss_stencil_gather_kernel(StencilArgs a) {
   const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (w < a.p.n_gather) gather_item<GRAD>(a, w, a.wavep + (a.p.n_splat + w) * kWaveTerms);
 }
 template <bool GRAD>
-__global__ __launch_bounds__(kBlock) void loss_stencil_splat_kernel(StencilArgs a) {
+__global__ __launch_bounds__(kBlock) SFM_WPE_SPLAT void loss_stencil_splat_kernel(StencilArgs a) {
   const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (w < a.p.n_splat) splat_item<GRAD>(a, w, a.wavep + w * kWaveTerms);
 }
