@@ -321,13 +321,14 @@ __global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __rest
   __shared__ double red[kBlock];
   const int s = blockIdx.x, t = t0 + blockIdx.y;
   const int nterm = 3 * d.N + 1;
-  const long per = (long)d.B * p.per_img;  // waves per (scale, source) image set
+  long per = (long)d.B * p.per_img;  // waves per (scale, source) image set
   long first;
   int comp;
   if (t < 3 * d.N) {
     first = ((long)s * d.N + t / 3) * per;
     comp = t % 3;
   } else {
+    per = (long)d.B * p.per_img_g;
     first = p.n_splat + (long)s * per;
     comp = 0;
   }
@@ -397,7 +398,7 @@ template <int N>
 #define SFM_WPE_BWD
 #endif
 #ifndef SFM_BWD_PAIR
-#define SFM_BWD_PAIR 2  // sources whose gathers are in flight together
+#define SFM_BWD_PAIR 1  // sources whose gathers are in flight together (1: 143 VGPRs = three waves per SIMD; 2: 190)
 #endif
 __global__ __launch_bounds__(kBlock) SFM_WPE_BWD
 void loss_warp_bwd_kernel(const float* __restrict__ tgt,
@@ -577,17 +578,22 @@ static inline bool dims_ok(const LossDims& d) {
   if (!(d.B > 0 && d.H > 0 && d.W > 0 && d.S > 0 && d.N >= 2 && d.N <= kMaxSrc && d.B <= 65535 && d.S <= 65535 &&
         (long)d.S * d.N * d.B <= 65535 && sfm_fits(d.H, d.W, 3 * d.N > 8 ? 3 * d.N : 8)))
     return false;
-  const StencilPlan sp = stencil_plan(d, 8);  // the smallest rows per wave = the most work items (32-bit in the kernels)
+  const StencilPlan sp = stencil_plan(d, 6, 6);  // the smallest rows per wave = the most work items (32-bit in the kernels)
   return sp.n_splat + sp.n_gather < 2147483647L;
 }
 
-// Tuning knob (experiments only): image rows per stencil wave; 0 = the heuristic of stencil_plan.
+// Tuning knobs (experiments only): image rows per stencil wave, splat side / gather side; 0 = the model of stencil_rows.
+static int env_rows(const char* name) {
+  const char* e = getenv(name);
+  const int r = e ? atoi(e) : 0;
+  return (r >= 1 && r <= 4096) ? r : 0;
+}
 static int stencil_rows_override() {
-  static const int v = [] {
-    const char* e = getenv("SFM_STENCIL_ROWS");
-    const int r = e ? atoi(e) : 0;
-    return (r >= 1 && r <= 4096) ? r : 0;
-  }();
+  static const int v = env_rows("SFM_STENCIL_ROWS");
+  return v;
+}
+static int stencil_rows_g_override() {
+  static const int v = env_rows("SFM_STENCIL_ROWS_G");
   return v;
 }
 
@@ -597,7 +603,7 @@ struct LossLayout {
 };
 static inline LossLayout loss_layout(const LossDims& d) {
   LossLayout l;
-  l.sp = stencil_plan(d, stencil_rows_override());
+  l.sp = stencil_plan(d, stencil_rows_override(), stencil_rows_g_override());
   l.w = loss_ws(d, l.sp);
   return l;
 }

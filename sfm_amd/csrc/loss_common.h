@@ -20,25 +20,53 @@ constexpr int kStripOwn = 60;
 constexpr int kWaveTerms = 4;  // per-wave partial sums: splat (A, M, V, -), gather (E, -, -, -)
 
 struct StencilPlan {
-  int strips;   // per image row
-  int rows;     // image rows owned by one wave
-  int chunks;   // per image column
-  int per_img;  // strips * chunks
+  int strips;     // per image row
+  int rows;       // image rows owned by one wave of the splat-side kernel
+  int chunks;     // per image column
+  int per_img;    // strips * chunks
+  int rows_g, chunks_g, per_img_g;  // the same for the gather-side kernel (its own register budget and occupancy)
   long n_splat, n_gather;  // work items (waves)
 };
 
-static inline StencilPlan stencil_plan(const LossDims& d, int rows_override) {
+// Rows per wave.  More rows = fewer halo rows per owned row ((rows + 4) / rows row steps), fewer rows = more waves.  A wave
+// issues at most one VALU instruction every ~6.4 cycles while a SIMD takes one every ~2.6 (tools/valu_bench.hip), so what
+// counts on a small problem is how the waves fill the resident slots (1024 SIMDs x `waves_per_simd`).  Measured at c2
+// (sweeps of SFM_STENCIL_ROWS / SFM_STENCIL_ROWS_G):
+//   * large problems (>= 6 rounds of resident waves even with long strips): the longest strips that keep 6 rounds;
+//   * small ones, `fill` set (gather side, 2 waves per SIMD): the strips that fill the resident slots exactly once - 2016
+//     waves on 2048 slots at c2, rows = 15: 98 us for the pair of kernels where rows = 8 took 104 and rows = 19 106;
+//   * small ones otherwise (splat side, 3 waves per SIMD): 8 rows - flat from 8 to 13, worse beyond.
+static inline int stencil_rows(long wave_columns, int H, int waves_per_simd, bool fill) {
+  const long slots = 1024L * waves_per_simd;
+  auto waves = [&](int rows) { return wave_columns * ((H + rows - 1) / rows); };
+  auto even = [&](int rows) { const int c = (H + rows - 1) / rows; return (H + c - 1) / c; };  // same chunks, equal rows
+  if (waves(8) >= 6 * slots) {
+    int rows = 64;
+    while (rows > 8 && waves(rows) < 6 * slots) --rows;
+    return even(rows);
+  }
+  if (fill) {
+    const long chunks = slots / (wave_columns > 0 ? wave_columns : 1);
+    if (chunks >= 1) {
+      const int rows = (int)((H + chunks - 1) / chunks);
+      if (rows >= 8 && rows <= 24) return even(rows);
+    }
+  }
+  return H < 8 ? (H > 0 ? H : 1) : 8;
+}
+
+static inline StencilPlan stencil_plan(const LossDims& d, int rows_override, int rows_g_override) {
   StencilPlan p;
   p.strips = (d.W + kStripOwn - 1) / kStripOwn;
-  const long imgs = (long)d.S * d.B * (d.N + (d.N >= 2 ? 1 : 0));
-  int rows = 64;  // fewer halo rows per owned row; shrink until the chip has enough waves
-  while (rows > 8 && imgs * p.strips * ((d.H + rows - 1) / rows) < 8192) rows >>= 1;
-  if (rows_override > 0) rows = rows_override;
-  p.rows = rows;
-  p.chunks = (d.H + rows - 1) / rows;
+  const long cols_s = (long)d.S * d.N * d.B * p.strips, cols_g = (long)d.S * d.B * p.strips;
+  p.rows = rows_override > 0 ? rows_override : stencil_rows(cols_s, d.H, 3, false);    // 146 VGPRs: 3 waves per SIMD
+  p.rows_g = rows_g_override > 0 ? rows_g_override : stencil_rows(cols_g, d.H, 2, true);  // 194 VGPRs: 2
+  p.chunks = (d.H + p.rows - 1) / p.rows;
+  p.chunks_g = (d.H + p.rows_g - 1) / p.rows_g;
   p.per_img = p.strips * p.chunks;
+  p.per_img_g = p.strips * p.chunks_g;
   p.n_splat = (long)d.S * d.N * d.B * p.per_img;
-  p.n_gather = d.N >= 2 ? (long)d.S * d.B * p.per_img : 0;
+  p.n_gather = d.N >= 2 ? (long)d.S * d.B * p.per_img_g : 0;
   return p;
 }
 
@@ -58,7 +86,10 @@ constexpr int STW = 64, STH = SFM_STH;  // splat: destination tile of one workgr
 #define SFM_SPLAT_PPT 4
 #endif
 constexpr int kSplatThreads = STW * STH / SFM_SPLAT_PPT;  // home pixels per thread
-constexpr int BTW = 64, BTH = 16;  // backward warp: pixel tile of one workgroup
+#ifndef SFM_BTH
+#define SFM_BTH 8  // 64x8: 3328 workgroups at c2 - finer than 64x16 against the 768 resident ones (quantisation: -9 %)
+#endif
+constexpr int BTW = 64, BTH = SFM_BTH;  // backward warp: pixel tile of one workgroup
 constexpr int kLossPPT = BTW * BTH / kBlock;  // pixels per thread in the backward warp kernel
 
 struct LossWs {

@@ -144,8 +144,8 @@ struct Item {
   int img, chunk, strip;
 };
 // 32-bit arithmetic (the item count is checked on the host): a 64-bit division pair here was ~7 % of a wave's instructions
-__device__ __forceinline__ Item split_item(long item, const StencilPlan& p) {
-  const unsigned u = (unsigned)item, strips = (unsigned)p.strips, chunks = (unsigned)p.chunks;
+__device__ __forceinline__ Item split_item(long item, int n_strips, int n_chunks) {
+  const unsigned u = (unsigned)item, strips = (unsigned)n_strips, chunks = (unsigned)n_chunks;
   Item it;
   const unsigned r = u / strips;
   it.strip = (int)(u - r * strips);
@@ -298,7 +298,7 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   SplatWave<GRAD> w;
   const LossDims d = a.d;
   w.d = d;
-  const Item it = split_item(item, a.p);
+  const Item it = split_item(item, a.p.strips, a.p.chunks);
   const int lane = threadIdx.x & 63;
   const int b = it.img % d.B, i = (it.img / d.B) % d.N;
   const int HW = d.H * d.W;
@@ -353,14 +353,14 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
 template <bool GRAD>
 __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, float* __restrict__ wavep_out) {
   const LossDims d = a.d;
-  const Item it = split_item(item, a.p);
+  const Item it = split_item(item, a.p.strips, a.p.chunks_g);
   const int lane = threadIdx.x & 63;
   const int s = it.img / d.B, b = it.img - s * d.B;
   const int HW = d.H * d.W;
   const int gx = it.strip * kStripOwn - 2 + lane;
   const bool col_in = gx >= 0 && gx < d.W;
   const bool own_col = lane >= 2 && lane < 62 && gx < d.W;
-  const int y0 = it.chunk * a.p.rows, y1 = min(y0 + a.p.rows, d.H);
+  const int y0 = it.chunk * a.p.rows_g, y1 = min(y0 + a.p.rows_g, d.H);
   const size_t gpix = (size_t)d.B * HW;
   const size_t o0 = (((size_t)s * 2 + 0) * gpix + (size_t)b * HW) * 3;
   const size_t o1 = (((size_t)s * 2 + 1) * gpix + (size_t)b * HW) * 3;
