@@ -393,7 +393,12 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
 // dL/dP accumulators of every source stay in registers, d_depth is summed in a register and the
 // 12-byte d_trans pieces of all sources are stored back to back, so each 128-byte line leaves L2 once).
 // grid: S*B*tiles blocks (1-D).  d_depth [S,B,H,W], d_trans [S,B,H,W,3N], dP partials [S][N*B][tiles][12].
-template <int N>
+// One launch handles the NL sources i_base .. i_base + NL - 1 of the d.N in the tensors (NL <= 2: the register budget of
+// three waves per SIMD; with all four sources of seq = 5 in one kernel it was 298 VGPRs = ONE wave per SIMD); launches
+// after the first add their share to d_depth (accumulate != 0).
+// GATHERED: these are sources 0, 1, the ones the min-reprojection term gathers (:168); NTC: d.N when known at compile time
+// (the seq = 3 case keeps its compile-time strides: 143 VGPRs instead of 154), else 0
+template <int NL, bool GATHERED, int NTC, int IB>
 #ifndef SFM_WPE_BWD
 #define SFM_WPE_BWD
 #endif
@@ -416,8 +421,12 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                float* __restrict__ d_trans,
                                                                float* __restrict__ dPp, float* __restrict__ Ovf,
                                                                const int* __restrict__ flags) {
+  constexpr int i_base = IB;
+  constexpr bool accumulate = IB != 0;
   __shared__ float red[4 * 12];
-  constexpr int C3 = 3 * N, NG = N < 2 ? N : 2;
+  constexpr int N = NL;  // sources of this launch
+  const int NT = NTC ? NTC : d.N, C3 = 3 * NT;
+  constexpr int NG = 2;  // d.N >= 2 (checked on the host)
   const int ntile = tiles_x * tiles_y;
   const int blk = xcd_contiguous(blockIdx.x, gridDim.x);  // (s*B + b)*ntile + tile
   const int tile = blk % ntile, sbi = blk / ntile, b = sbi % d.B, s = sbi / d.B;
@@ -427,16 +436,16 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
   const size_t sb = ((size_t)s * d.B + b) * HW;
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
   // gl = dL/d loss.  The loss itself is one thread's job
-  if (blockIdx.x == 0 && threadIdx.x == 0) *loss_out = loss_value(partials, d.S, N, n_elem);
-  const size_t hb_plane = (size_t)d.S * N * d.B * HW * 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && i_base == 0) *loss_out = loss_value(partials, d.S, NT, n_elem);
+  const size_t hb_plane = (size_t)d.S * NT * d.B * HW * 4;
   Pose ps[N];
   float kv[N], dp[N][12];
   bool clr[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    ps[i] = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
-    kv[i] = gl * loss_kv(partials, N, s, i, inv_n);  // wave-uniform (scalar loads)
-    clr[i] = flags[(s * N + i) * d.B + b] != 0;
+    ps[i] = load_pose(params + ((size_t)(i_base + i) * d.B + b) * SFM_PARAM_STRIDE);
+    kv[i] = gl * loss_kv(partials, NT, s, i_base + i, inv_n);  // wave-uniform (scalar loads)
+    clr[i] = flags[(s * NT + i_base + i) * d.B + b] != 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) dp[i][k] = 0.0f;
   }
@@ -453,7 +462,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
     n_dep = depth[sb + p];
     n_tv = ld3(tgt + (img + p) * 3);
 #pragma unroll
-    for (int i = 0; i < N; ++i) n_t[i] = ld3(trans + (sb + p) * C3 + 3 * i);
+    for (int i = 0; i < N; ++i) n_t[i] = ld3(trans + (sb + p) * C3 + 3 * (i_base + i));
   };
   fetch1(0);
 #pragma unroll 1
@@ -470,7 +479,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
     const int p = v * d.W + u;
     const float gxc = grid_coord(u, step_x, xmax), gyc = grid_coord(v, step_y, ymax);
     float ddsum = 0.0f;
-    float dts[C3];
+    float dts[3 * N];
 #pragma unroll
     for (int i0 = 0; i0 < N; i0 += SFM_BWD_PAIR) {
       constexpr int kPair = SFM_BWD_PAIR;
@@ -494,15 +503,16 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
       for (int j = 0; j < kPair; ++j) {
         const int i = i0 + j;
         if (i >= N) continue;
-        const size_t simg = ((size_t)s * N + i) * d.B + b;
+        const int ig = i_base + i;  // source index in the tensors
+        const size_t simg = ((size_t)s * NT + ig) * d.B + b;
         // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
         if (clr[i]) reinterpret_cast<float4*>(Ovf + simg * HW * 4)[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* hb = Hb + simg * HW * 4;  // part A; part B one plane further
-        if (i < NG) {
-          const float* sbase = src + img * C3 + 3 * i;
+        if (GATHERED) {
+          const float* sbase = src + img * C3 + 3 * ig;
 #pragma unroll
           for (int q = 0; q < 4; ++q) ta[j][q] = ld3(sbase + (size_t)idx[j][q] * C3);
-          go[j] = ld3(dG + ((((size_t)s * NG + i) * d.B + b) * HW + p) * 3);
+          go[j] = ld3(dG + ((((size_t)s * NG + ig) * d.B + b) * HW + p) * 3);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -516,7 +526,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
         const int i = i0 + j;
         if (i >= N) continue;
         float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
-        if (i < NG) {
+        if (GATHERED) {
           const float wx0 = c[j].fx1 - g[j].x, wx1 = g[j].x - c[j].fx0, wy0 = c[j].fy1 - g[j].y, wy1 = g[j].y - c[j].fy0;
           const f3 a = ta[j][0], bb = ta[j][1], cc = ta[j][2], dd = ta[j][3], gq = go[j];
           gx_ = gl * (gq.x * (wy0 * (cc.x - a.x) + wy1 * (dd.x - bb.x)) + gq.y * (wy0 * (cc.y - a.y) + wy1 * (dd.y - bb.y)) +
@@ -541,14 +551,15 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
         ddsum += dd_;
       }
     }
-    d_depth[sb + p] = ddsum;
+    d_depth[sb + p] = accumulate ? d_depth[sb + p] + ddsum : ddsum;
 #pragma unroll
-    for (int i = 0; i < N; ++i) st3(d_trans + (sb + p) * C3 + 3 * i, dts[3 * i], dts[3 * i + 1], dts[3 * i + 2]);
+    for (int i = 0; i < N; ++i)
+      st3(d_trans + (sb + p) * C3 + 3 * (i_base + i), dts[3 * i], dts[3 * i + 1], dts[3 * i + 2]);
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if (i) __syncthreads();  // red is reused per source
-    block_sum_store<12>(dp[i], red, dPp + ((((size_t)s * N + i) * d.B + b) * ntile + tile) * 12);
+    block_sum_store<12>(dp[i], red, dPp + ((((size_t)s * NT + i_base + i) * d.B + b) * ntile + tile) * 12);
   }
 }
 
@@ -753,13 +764,16 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   }
   { StageTimer t(ST_WARP_BWD, stream);
   const dim3 grid((unsigned)((long)S * B * w.nblk_bwd));
-#define SFM_LAUNCH_BWD(NSRC)                                                                                          \
-  hipLaunchKernelGGL(loss_warp_bwd_kernel<NSRC>, grid, dim3(kBlock), 0, stream, tgt, src, depth, trans, params,      \
+#define SFM_LAUNCH_BWD(NSRC, IBASE, NTC)                                                                                 \
+  hipLaunchKernelGGL((loss_warp_bwd_kernel<NSRC, (IBASE) == 0, NTC, IBASE>), grid, dim3(kBlock), 0, stream, tgt, src, depth, trans, params,      \
                      ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, 1.0 / (double)n_elem_global, gloss,       \
                      loss_out, d, sfm_lin_step(W),                                                                   \
                      sfm_lin_step(H), w.btiles_x, w.btiles_y,                                                        \
                      d_depth, d_trans, ws + w.dPp, ws + w.Ovf, flags)
-  if (N == 2) SFM_LAUNCH_BWD(2); else if (N == 3) SFM_LAUNCH_BWD(3); else SFM_LAUNCH_BWD(4);
+  // sources 0, 1 (the gathered ones); then the rest, two at a time, adding into d_depth
+  if (N == 2) SFM_LAUNCH_BWD(2, 0, 2); else SFM_LAUNCH_BWD(2, 0, 0);
+  if (N == 3) SFM_LAUNCH_BWD(1, 2, 0);
+  if (N == 4) SFM_LAUNCH_BWD(2, 2, 0);
 #undef SFM_LAUNCH_BWD
   }
   int rc = sfm_last_error();

@@ -9,6 +9,8 @@ CASES = [("c2 416x128 B=8 S=4 N=2", 8, 128, 416, 4, 2, False),
          ("c3 1248x384 B=4/GPU (32 over 8 GPUs) S=4 N=2", 4, 384, 1248, 4, 2, False),
          ("c3 1248x384 B=16/GPU (32 over 2 GPUs) S=4 N=2", 16, 384, 1248, 4, 2, False),
          ("c4 2048x1024 B=8/GPU (64 over 8 GPUs) S=4 N=4", 8, 1024, 2048, 4, 4, True)]
+if os.environ.get("SFM_CASES"):  # e.g. SFM_CASES=1,2
+    CASES = [CASES[int(k)] for k in os.environ["SFM_CASES"].split(",")]
 for label, B, H, W, S, N, city in CASES:
     inp = synth.to_device(synth.make_inputs(B, H, W, S=S, N=N, seed=synth.SEED, cityscapes=city), dev)
     tgt, src, K, pose = inp["tgt"], inp["src"], inp["K"], inp["pose"]
