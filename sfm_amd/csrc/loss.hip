@@ -41,7 +41,10 @@ constexpr int kCacheTX = 2, kCacheTY = 4, kCacheW = 2 * kCacheTX + 1, kCacheH = 
 #ifndef SFM_REACH_MIN
 #define SFM_REACH_MIN 6
 #endif
-constexpr int kReachAdd = SFM_REACH_ADD, kReachMin = SFM_REACH_MIN, kReachMax = 16;
+#ifndef SFM_REACH_MAX
+#define SFM_REACH_MAX 32  // c4 (Cityscapes intrinsics, 20-90 px shifts): 16 left 6 % of the pixels to the overflow path; 32: splat -23 %
+#endif
+constexpr int kReachAdd = SFM_REACH_ADD, kReachMin = SFM_REACH_MIN, kReachMax = SFM_REACH_MAX;
 
 // ------------------------------------------------------------------ fused warp forward
 // The forward splat (utils.py:419-470) without global atomics in the common case.
