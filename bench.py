@@ -153,9 +153,46 @@ def total_loss_leg(dev, reps: int = 50) -> dict:
         loss = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    return {"workload": f"total_loss fwd+bwd from raw pyramids (scale s at {H}>>s x {W}>>s), B={B}, smooth_weight=0.01, "
+    # the same call sequence captured once as a HIP graph and replayed (inputs copied into its static buffers per call)
+    g = sfm_amd.GraphedTotalLoss(inp["tgt"], inp["src"], inp["K"], raw, pose, trans, smooth_weight=0.01)
+    raw_d, trans_d, pose_d = [t.detach() for t in raw], [t.detach() for t in trans], pose.detach()
+    for _ in range(10):
+        gl = g(raw_d, pose_d, trans_d)[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gl = g(raw_d, pose_d, trans_d)[0]
+    torch.cuda.synchronize()
+    ms_graph = (time.perf_counter() - t0) / reps * 1e3
+    graph_part = {"ms_per_call_hip_graph": ms_graph, "Gpix_per_s_hip_graph": B * H * W * S * N * 2 / (ms_graph * 1e-3) / 1e9,
+                  "loss_hip_graph": float(gl.detach())}
+    return {**graph_part, "workload": f"total_loss fwd+bwd from raw pyramids (scale s at {H}>>s x {W}>>s), B={B}, smooth_weight=0.01, "
                         f"through sfm_amd.multi_scale_loss (autograd, host overhead included)",
             "ms_per_call": ms, "Gpix_per_s": B * H * W * S * N * 2 / (ms * 1e-3) / 1e9, "loss": float(loss.detach())}
+
+
+def loader_leg(dev, reps: int = 50) -> dict:
+    """decoded uint8 snippets resident in HBM -> tgt / src stack in [-1, 1] + multi-scale
+    intrinsics, with the training augmentation (sfm_snippet_unpack: two launches)."""
+    from sfm_amd.data_loader import AugmentDraws, snippet_unpack
+    g = torch.Generator().manual_seed(8964)
+    seq = torch.randint(0, 256, (B, H, (N + 1) * W, 3), dtype=torch.uint8, generator=g).to(dev)
+    k = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
+    d = AugmentDraws(1.1, (0.9, 1.0, 1.1), True, 1.2)
+    for _ in range(5):
+        snippet_unpack(seq, k, H, W, N, S, d)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        snippet_unpack(seq, k, H, W, N, S, d)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = B * H * W * (N + 1) * (3 * 2 + 12)  # uint8 read twice (sums, then apply), fp32 written once
+    return {"workload": f"snippet unpack + augmentation + preprocess, B={B} {W}x{H} seq={N + 1}, through "
+                        f"sfm_amd.snippet_unpack (host overhead included)",
+            "ms_per_batch": ms, "snippets_per_s": B / (ms * 1e-3), "algorithmic_GBps": nbytes / (ms * 1e-3) / 1e9}
 
 
 def main() -> None:
@@ -294,6 +331,7 @@ def main() -> None:
             line["config"]["config5_step_ms"] = ms_step + line["aspp"]["ms"]  # ASPP convs + warp loss, fwd + bwd
         if world == 1 and not args.no_aspp:
             line["end_to_end"] = total_loss_leg(dev)
+            line["loader"] = loader_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth.SEED)
         print(json.dumps(line), flush=True)

@@ -15,7 +15,7 @@ from . import _lib  # noqa: F401
 from .utils import (bilinear_project, bilinear_sampler, cam2pixel, corner_indices, euler2mat, meshgrid,  # noqa: F401
                     pixel2cam, pose_vec2mat, project_coords, projective_inverse_warp, projective_warp, ssim_value,
                     tf_ssim)
-from .loss import multi_scale_loss  # noqa: F401
+from .loss import GraphedTotalLoss, multi_scale_loss  # noqa: F401
 from .pyramid import compute_smooth_loss, normalize_disp, resize_bilinear  # noqa: F401
 from .aspp import batch_norm_elu, conv1x1, conv2d_bn_elu, dilated_conv3x3, disp_bottleneck_dense  # noqa: F401
 from .data_loader import AugmentDraws, DataLoader, snippet_unpack  # noqa: F401
@@ -24,7 +24,7 @@ from ._lib import SfmAmdError  # noqa: F401
 
 __all__ = ["projective_inverse_warp", "projective_warp", "bilinear_sampler", "bilinear_project", "tf_ssim",
            "ssim_value", "pose_vec2mat", "euler2mat", "meshgrid", "pixel2cam", "cam2pixel", "project_coords",
-           "corner_indices", "multi_scale_loss", "compute_smooth_loss", "resize_bilinear", "normalize_disp",
+           "corner_indices", "multi_scale_loss", "GraphedTotalLoss", "compute_smooth_loss", "resize_bilinear", "normalize_disp",
            "dilated_conv3x3", "batch_norm_elu", "conv2d_bn_elu", "conv1x1", "disp_bottleneck_dense",
            "DataLoader", "AugmentDraws", "snippet_unpack",
            "SfmAmdError"]
