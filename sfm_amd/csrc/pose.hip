@@ -66,13 +66,8 @@ __device__ void matmul_seq(const T* a, const T* b, T* o) {  // k-ordered, no FMA
 
 constexpr float kPiF = 3.14159274101257324f;  // fp32(np.pi)
 
-__device__ void euler_mats(float rx, float ry, float rz, float* X, float* Y, float* Z) {
-  rz = fminf(fmaxf(rz, -kPiF), kPiF);
-  ry = fminf(fmaxf(ry, -kPiF), kPiF);
-  rx = fminf(fmaxf(rx, -kPiF), kPiF);
-  float sz = (float)sin((double)rz), cz = (float)cos((double)rz);
-  float sy = (float)sin((double)ry), cy = (float)cos((double)ry);
-  float sx = (float)sin((double)rx), cx = (float)cos((double)rx);
+// rotation factors from the six correctly rounded sines / cosines of the clipped angles
+__device__ void euler_mats(float sx, float cx, float sy, float cy, float sz, float cz, float* X, float* Y, float* Z) {
   float z_[9] = {cz, -sz, 0.f, sz, cz, 0.f, 0.f, 0.f, 1.f};
   float y_[9] = {cy, 0.f, sy, 0.f, 1.f, 0.f, -sy, 0.f, cy};
   float x_[9] = {1.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, sx, cx};
@@ -80,16 +75,29 @@ __device__ void euler_mats(float rx, float ry, float rz, float* X, float* Y, flo
 }
 
 // items = n_src * B, item j = i * B + b.  pose element (b, i, k) at pose[b*pose_sb + i*pose_si + k].
-__global__ void pose_setup_kernel(const float* __restrict__ pose, long pose_sb, long pose_si,
-                                  const float* __restrict__ K, int B, int n_src, int inverse_pose,
-                                  float* __restrict__ params) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= B * n_src) return;
+// Four lanes per item: lanes 0..2 of a group each evaluate the fp64 sincos of one angle (the kernel is one wave's
+// latency chain in front of every step; the three evaluations were 2/3 of it when one thread walked them), lane 0
+// collects them by shuffles and does the rest.
+__global__ __launch_bounds__(64) void pose_setup_kernel(const float* __restrict__ pose, long pose_sb, long pose_si,
+                                                        const float* __restrict__ K, int B, int n_src, int inverse_pose,
+                                                        float* __restrict__ params) {
+  const int items = B * n_src;
+  const int jr = blockIdx.x * 16 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const int j = jr < items ? jr : items - 1;  // idle groups redo the last item: every lane takes part in the shuffles
   int i = j / B, b = j - i * B;
   const float* pv = pose + b * pose_sb + i * pose_si;
   const float* k3 = K + (long)b * 9;
+  const float ang = fminf(fmaxf(pv[3 + (sub < 3 ? sub : 0)], -kPiF), kPiF);  // sub 0, 1, 2: rx, ry, rz
+  double sd, cd;
+  sincos((double)ang, &sd, &cd);
+  const float sf = (float)sd, cf = (float)cd;
+  const int base = threadIdx.x & ~3;
+  const float sx = __shfl(sf, base, 64), cx = __shfl(cf, base, 64);
+  const float sy = __shfl(sf, base + 1, 64), cy = __shfl(cf, base + 1, 64);
+  const float sz = __shfl(sf, base + 2, 64), cz = __shfl(cf, base + 2, 64);
+  if (sub != 0 || jr >= items) return;
   float X[9], Y[9], Z[9], XY[9], R[9];
-  euler_mats(pv[3], pv[4], pv[5], X, Y, Z);
+  euler_mats(sx, cx, sy, cy, sz, cz, X, Y, Z);
   matmul_seq<3>(X, Y, XY);
   matmul_seq<3>(XY, Z, R);
   float T[16] = {R[0], R[1], R[2], pv[0], R[3], R[4], R[5], pv[1], R[6], R[7], R[8], pv[2], 0.f, 0.f, 0.f, 1.f};
@@ -247,7 +255,7 @@ extern "C" int sfm_pose_setup(const float* pose, long pose_sb, long pose_si, con
                               int inverse_pose, float* params, void* stream) {
   if (!pose || !K || !params || B <= 0 || n_src <= 0) return SFM_ERR_ARG;
   int items = B * n_src;
-  hipLaunchKernelGGL(pose_setup_kernel, dim3((items + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, pose_sb,
+  hipLaunchKernelGGL(pose_setup_kernel, dim3((items + 15) / 16), dim3(64), 0, (hipStream_t)stream, pose, pose_sb,
                      pose_si, K, B, n_src, inverse_pose, params);
   return sfm_last_error();
 }
