@@ -44,6 +44,10 @@ constexpr int kCacheTX = 2, kCacheTY = 4, kCacheW = 2 * kCacheTX + 1, kCacheH = 
 #ifndef SFM_REACH_MAX
 #define SFM_REACH_MAX 32  // c4 (Cityscapes intrinsics, 20-90 px shifts): 16 left 6 % of the pixels to the overflow path; 32: splat -23 %
 #endif
+#ifndef SFM_REACH_MUL
+#define SFM_REACH_MUL 1.0f
+#endif
+constexpr float kReachMul = SFM_REACH_MUL;  // margin proportional to the sampled spread (the variation between samples grows with it)
 constexpr int kReachAdd = SFM_REACH_ADD, kReachMin = SFM_REACH_MIN, kReachMax = SFM_REACH_MAX;
 
 // ------------------------------------------------------------------ fused warp forward
@@ -122,8 +126,8 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
   int4 o;
   o.x = (mx == mx) ? (int)rintf(fminf(fmaxf(mx, -32768.0f), 32767.0f)) : 0;
   o.y = (my == my) ? (int)rintf(fminf(fmaxf(my, -32768.0f), 32767.0f)) : 0;
-  o.z = (hx == hx) ? (int)fminf(fmaxf(ceilf(hx) + (float)radd, (float)rmin), (float)rmax) : rmin;
-  o.w = (hy == hy) ? (int)fminf(fmaxf(ceilf(hy) + (float)radd, (float)rmin), (float)rmax) : rmin;
+  o.z = (hx == hx) ? (int)fminf(fmaxf(ceilf(hx * kReachMul) + (float)radd, (float)rmin), (float)rmax) : rmin;
+  o.w = (hy == hy) ? (int)fminf(fmaxf(ceilf(hy * kReachMul) + (float)radd, (float)rmin), (float)rmax) : rmin;
   shift[k] = o;
 }
 
@@ -182,7 +186,6 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   const size_t sb = ((size_t)s * d.B + b) * HW;      // pixel offset of (s, b)
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
   float* __restrict__ ovf = Ovf + (size_t)img * HW * 4;
-  bool flagged = false;
 
   // The scan loop is software pipelined by hand: the coalesced first stage (depth, translations, tgt) of
   // the NEXT scanned pixel is in flight while this one is processed, and a home pixel's four source taps
@@ -281,8 +284,10 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
             atomicAdd(o + 1, tv.y * sw.g[q]);
             atomicAdd(o + 2, tv.z * sw.g[q]);
             atomicAdd(o + 3, sw.g[q]);
+            // the DESTINATION tile's flag: only its consumers (stencil strips over it, the backward tile that clears it)
+            // pay for the side accumulator.  Plain stores of 1: every racer writes the same value
+            flags[(size_t)img * (tiles_x * tiles_y) + ((unsigned)cy[q] / STH) * tiles_x + (unsigned)cx[q] / STW] = 1;
           }
-        flagged = true;
       }
     }
     if (do_gather) {  // gather (utils.py:297-335)
@@ -294,7 +299,6 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
           ((w00 * ta.z + w01 * tb.z) + w10 * tc.z) + w11 * td.z);
     }
   }
-  if (flagged) flags[img] = 1;
   __syncthreads();
   float* __restrict__ accg = Acc + (size_t)img * HW * 4;
   for (int k = threadIdx.x; k < TP; k += kSplatThreads) {
@@ -305,12 +309,17 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   }
 }
 
-// Zeroes the side accumulator of the images whose flag is raised (grid (blocks, S*N*B)).
+// Zeroes the side accumulator under the raised flags (forward-only steps).  grid (tiles per image, S*N*B).
 __global__ __launch_bounds__(kBlock) void loss_ovf_clear_kernel(float* __restrict__ Ovf, const int* __restrict__ flags,
-                                                                int HW) {
-  if (!flags[blockIdx.y]) return;
-  float4* o = reinterpret_cast<float4*>(Ovf + (size_t)blockIdx.y * HW * 4);
-  for (int p = blockIdx.x * kBlock + threadIdx.x; p < HW; p += gridDim.x * kBlock) o[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                                                int H, int W, int tiles_x) {
+  const int ntile = gridDim.x;
+  if (!flags[(size_t)blockIdx.y * ntile + blockIdx.x]) return;
+  const int x0 = (blockIdx.x % tiles_x) * STW, y0 = (blockIdx.x / tiles_x) * STH;
+  float4* o = reinterpret_cast<float4*>(Ovf + (size_t)blockIdx.y * H * W * 4);
+  for (int k = threadIdx.x; k < STW * STH; k += kBlock) {
+    const int u = x0 + (k & (STW - 1)), v = y0 + k / STW;
+    if (u < W && v < H) o[(size_t)v * W + u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 // ------------------------------------------------------------------ reduce
@@ -448,7 +457,8 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
   for (int i = 0; i < N; ++i) {
     ps[i] = load_pose(params + ((size_t)(i_base + i) * d.B + b) * SFM_PARAM_STRIDE);
     kv[i] = gl * loss_kv(partials, NT, s, i_base + i, inv_n);  // wave-uniform (scalar loads)
-    clr[i] = flags[(s * NT + i_base + i) * d.B + b] != 0;
+    // BTW == STW and BTH divides STH: this tile lies inside splat tile (y0 / STH, x0 / STW)
+    clr[i] = flags[((size_t)(s * NT + i_base + i) * d.B + b) * (tiles_x * ((d.H + STH - 1) / STH)) + (y0 / STH) * tiles_x + x0 / STW] != 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) dp[i][k] = 0.0f;
   }
@@ -649,7 +659,7 @@ extern "C" int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, in
   hipStream_t stream = (hipStream_t)stream_;
   hipError_t e = hipMemsetAsync(ws + w.Ovf, 0, (size_t)S * N * B * H * W * 4 * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(ws + w.flags, 0, (size_t)w.n_img * sizeof(int), stream);
+  e = hipMemsetAsync(ws + w.flags, 0, (size_t)w.n_flags * sizeof(int), stream);
   return e == hipSuccess ? SFM_OK : (int)e;
 }
 
@@ -680,7 +690,7 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
     rc = sfm_last_error();
     if (rc) return rc;
   }
-  StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, ws + w.Hb, ws + w.dG, ws + w.wavep, d, l.sp,
+  StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, w.stiles_x, w.stiles_y, ws + w.Hb, ws + w.dG, ws + w.wavep, d, l.sp,
                 (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global)};
   if (phases == 3) {
     { StageTimer t(ST_STENCIL, stream);
@@ -761,8 +771,9 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
     { StageTimer t(ST_FINALIZE, stream);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, loss_out,
                        (const double*)nullptr); }
-    hipLaunchKernelGGL(loss_ovf_clear_kernel, dim3(64, w.n_img), dim3(kBlock), 0, stream, ws + w.Ovf, flags, H * W);
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_img * sizeof(int), stream);
+    hipLaunchKernelGGL(loss_ovf_clear_kernel, dim3(w.stiles_x * w.stiles_y, w.n_img), dim3(kBlock), 0, stream, ws + w.Ovf, flags,
+                       H, W, w.stiles_x);
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_flags * sizeof(int), stream);
     return e != hipSuccess ? (int)e : sfm_last_error();
   }
   { StageTimer t(ST_WARP_BWD, stream);
@@ -785,7 +796,7 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   StageTimer t(ST_POSE_GRAD, stream);
   // the last kernel of the step also lowers the overflow flags (Ovf itself was re-zeroed by warp_bwd)
   return sfm_launch_pose_grad(pose, 6L * N, 6L, K, ws + w.dPp, S, w.nblk_bwd, B, N, 0, 1.0f, d_pose, 6L * N, 6L, flags,
-                              w.n_img, stream);
+                              (int)w.n_flags, stream);
 }
 
 // ---- measurement aid (bench.py): per-launch HIP-event timing of the two calls above ----

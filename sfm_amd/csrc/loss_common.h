@@ -91,10 +91,12 @@ constexpr int kSplatThreads = STW * STH / SFM_SPLAT_PPT;  // home pixels per thr
 #endif
 constexpr int BTW = 64, BTH = SFM_BTH;  // backward warp: pixel tile of one workgroup
 constexpr int kLossPPT = BTW * BTH / kBlock;  // pixels per thread in the backward warp kernel
+static_assert(BTW == STW && STH % BTH == 0, "a backward tile lies inside one splat tile (per-tile overflow flags)");
 
 struct LossWs {
   size_t G, Acc, Ovf, Hb, dG, wavep, dPp, coef, shift, flags, total;
   int nblk_bwd, btiles_x, btiles_y, stiles_x, stiles_y, n_img;
+  long n_flags;  // one overflow flag per (image, splat tile)
 };
 
 static inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
@@ -119,7 +121,8 @@ static inline LossWs loss_ws(const LossDims& d, const StencilPlan& sp) {
   w.dPp = o; o += up4((size_t)d.S * d.N * d.B * w.nblk_bwd * 12);
   w.coef = o; o += 64;
   w.shift = o; o += (size_t)w.n_img * w.stiles_x * w.stiles_y * 4;
-  w.flags = o; o += up4((size_t)w.n_img);
+  w.n_flags = (long)w.n_img * w.stiles_x * w.stiles_y;
+  w.flags = o; o += up4((size_t)w.n_flags);
   w.total = o;
   return w;
 }
@@ -130,7 +133,8 @@ struct StencilArgs {
   const float* G;
   const float* Acc;
   const float* Ovf;
-  const int* flags;
+  const int* flags;  // [n_img][stiles_y][stiles_x]: the splat tile holds overflow contributions in Ovf
+  int stiles_x, stiles_y;
   float* Hb;
   float* dG;
   float* wavep;

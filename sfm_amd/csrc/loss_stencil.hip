@@ -309,7 +309,17 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   w.y0 = it.chunk * a.p.rows;
   w.y1 = min(w.y0 + a.p.rows, d.H);
   w.acc = a.Acc + (size_t)it.img * HW * 4;
-  w.ovf = a.flags[it.img] ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;  // wave-uniform
+  // side accumulator: only if one of the splat tiles under this strip (halo included) holds overflow contributions.
+  // Wave-uniform: the strip's first column and its rows are.
+  bool any_ovf = false;
+  {
+    const int c0 = max(it.strip * kStripOwn - 2, 0), c1 = min(it.strip * kStripOwn + 61, d.W - 1);
+    const int r0 = max(w.y0 - 2, 0), r1 = min(w.y1 + 1, d.H - 1);
+    const int* __restrict__ fl = a.flags + (size_t)it.img * (a.stiles_x * a.stiles_y);
+    for (int ty = r0 / STH; ty <= r1 / STH; ++ty)
+      for (int tx = c0 / STW; tx <= c1 / STW; ++tx) any_ovf |= fl[ty * a.stiles_x + tx] != 0;
+  }
+  w.ovf = any_ovf ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;
   w.sp = a.src + (size_t)b * HW * w.C3 + 3 * i;
   w.hb = a.Hb + (size_t)it.img * HW * 4;  // part A; part B one plane further
   w.hb_plane = (size_t)d.S * d.N * d.B * HW * 4;

@@ -46,11 +46,13 @@ class LossEngine:
             call("sfm_loss_workspace_init", ptr(self.ws), B, H, W, S, N, stream_of(self.ws))
 
     def overflow_state(self):
-        """(number of raised overflow flags, max |Ovf|) - both 0 between steps (test / debug aid)."""
+        """(number of raised overflow flags - one per (image, 64x32 splat tile) -, max |Ovf|): both 0 between steps
+        (test / debug aid)."""
         B, H, W, S, N = self.dims
         n_acc = S * N * B * H * W * 4
         ovf = self.ws[n_acc:2 * n_acc]                       # workspace map of csrc/loss.hip: Acc, Ovf, ...
-        flags = self.ws[-((S * N * B + 3) // 4 * 4):].view(torch.int32)[:S * N * B]
+        n_flags = S * N * B * ((W + 63) // 64) * ((H + 31) // 32)
+        flags = self.ws[-((n_flags + 3) // 4 * 4):].view(torch.int32)[:n_flags]
         return int((flags != 0).sum()), float(ovf.abs().max())
 
     def forward_partials(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool = True,

@@ -28,7 +28,10 @@ for label, B, H, W, S, N, city in CASES:
     for _ in range(n): out = step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     units = B * H * W * S * N * 2
-    nf, _ = eng.overflow_state()
+    eng.forward_partials(tgt, src, K, depth, pose, trans, ne, True); torch.cuda.synchronize()
+    nf, _ = eng.overflow_state()  # flags raised by a forward (the backward lowers them)
+    eng.backward(tgt, src, K, depth, pose, trans, eng.forward_partials(tgt, src, K, depth, pose, trans, ne, True), ne, 1.0, True)
+    print(f"   overflow flags raised: {nf} of {S * N * B} images", flush=True)
     import ctypes
     from sfm_amd import _lib
     lib = _lib.load(); st = (ctypes.c_float * 7)()

@@ -17,7 +17,7 @@ n_acc=S*N*B*H*W*4
 ovf = eng.ws[n_acc:2*n_acc].view(-1,4)
 print("flags raised", nf, "of", S*N*B, "ovf pixels nonzero frac", float((ovf[:,3]!=0).float().mean()))
 n_img = S*N*B; stx=(W+63)//64; sty=(H+31)//32
-fl = (n_img+3)//4*4; sh = n_img*stx*sty*4
+fl = (n_img*stx*sty+3)//4*4; sh = n_img*stx*sty*4
 tab = eng.ws[-(fl+sh):-fl].view(torch.int32).view(-1,4).cpu()
 import collections
 print("shift x", tab[:,0].min().item(), tab[:,0].max().item(), "y", tab[:,1].min().item(), tab[:,1].max().item())
