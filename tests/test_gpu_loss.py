@@ -38,6 +38,7 @@ def _gpu(inp, dev, fused, smooth_weight=0.0):
     (1, 37, 53, 3, 2, 0.05, True),     # ragged: tiles and blocks with tails
     (2, 32, 64, 4, 2, 0.01, False),    # pyramid inputs, resized as SfMLearner_uni.py:91,113
     (1, 24, 40, 2, 4, 0.02, True),     # seq=5: sources 2,3 only feed the splat terms (quirk 3)
+    (2, 20, 36, 2, 3, 0.02, True),     # three sources: the backward's second launch handles a single one
     (1, 128, 416, 4, 2, 0.01, True),   # one KITTI snippet, 4 scales
 ])
 @pytest.mark.parametrize("fused", [True, False])
