@@ -206,6 +206,14 @@ int sfm_aspp_conv3x3_bwd_data(const float* gout, const float* w, int B, int H, i
 int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, int rate,
                                 float* gw, float* ws, void* stream);
 
+/* The same slim.conv2d under is_training=False (the inference graphs, test_kitti_depth_con.py:19-65; arg-scope
+ * nets.py:653-656 -> resnet/resnet_utils.py:232-251): convolution, batch norm on the moving statistics
+ * y = gamma (x - moving_mean) / sqrt(moving_var + eps) + beta (gamma / beta may be NULL = 1 / 0), tf.nn.elu if act != 0 -
+ * in ONE pass: the normalisation and activation are applied where the MFMA kernel stores its sums.  ws as above. */
+int sfm_aspp_conv3x3_bn_act_infer(const float* in, const float* w, const float* gamma, const float* beta,
+                                  const float* moving_mean, const float* moving_var, float eps, int act, int B, int H,
+                                  int W, int Cin, int Cout, int rate, float* out, float* ws, void* stream);
+
 /* The 1x1 convolutions of the same block (nets.py:455, 456, 461, 466, 470): slim.conv2d(x, Cout, [1, 1]) itself, w
  * [1,1,Cin,Cout], through the same implicit-GEMM kernels (centre tap only).  ws: the 3x3 workspace of the shape. */
 int sfm_aspp_conv1x1_fwd(const float* in, const float* w, int B, int H, int W, int Cin, int Cout, float* out, float* ws,

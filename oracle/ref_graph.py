@@ -538,6 +538,14 @@ def batch_norm_elu(x_nhwc: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Opt
     return F.elu(z) if activation else z
 
 
+def batch_norm_infer(x_nhwc: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor, moving_var: Tensor,
+                     epsilon: float = 1e-5, activation: bool = True) -> Tensor:
+    """``slim.batch_norm(..., is_training=False)`` + ``tf.nn.elu``: the moving statistics instead of the batch's
+    (FusedBatchNorm, is_training=False: y = (x - mean) * rsqrt(var + eps) * gamma + beta)."""
+    z = gamma * ((x_nhwc - moving_mean) * torch.rsqrt(moving_var + epsilon)) + beta
+    return F.elu(z) if activation else z
+
+
 def conv1x1(x_nhwc: Tensor, w_hwio: Tensor) -> Tensor:
     """``slim.conv2d(x, Cout, [1, 1])`` without normaliser / activation (nets.py:455, 456, 461, 466, 470)."""
     return x_nhwc @ w_hwio[0, 0]

@@ -138,10 +138,31 @@ def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor =
 
 
 def conv2d_bn_elu(x: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, rate: int, moving_mean: Tensor = None,
-                  moving_var: Tensor = None, decay: float = BN_DECAY, epsilon: float = BN_EPSILON) -> Tensor:
+                  moving_var: Tensor = None, decay: float = BN_DECAY, epsilon: float = BN_EPSILON,
+                  is_training: bool = True, activation: bool = True) -> Tensor:
     """One ``slim.conv2d(x, Cout, [3, 3], rate=rate)`` of ``disp_bottleneck_dense`` under its arg-scope
-    (nets.py:457, 458, 463): dilated convolution (no bias: a normaliser is set), batch norm, ELU."""
-    return batch_norm_elu(dilated_conv3x3(x, w, rate), gamma, beta, moving_mean, moving_var, decay, epsilon)
+    (nets.py:457, 458, 463): dilated convolution (no bias: a normaliser is set), batch norm, ELU.
+    ``is_training=False`` (the inference graphs, test_kitti_depth_con.py:19-65): batch norm on the moving statistics
+    and the ELU are applied where the MFMA kernel stores its sums - one pass, forward only."""
+    if is_training:
+        return batch_norm_elu(dilated_conv3x3(x, w, rate), gamma, beta, moving_mean, moving_var, decay, epsilon, activation)
+    x = _check(x, "x", 4)
+    w = _check(w, "w", 4)
+    if w.shape[0] != 3 or w.shape[1] != 3 or w.shape[2] != x.shape[3]:
+        raise ValueError(f"w must be [3, 3, {x.shape[3]}, Cout], got {tuple(w.shape)}")
+    if moving_mean is None or moving_var is None:
+        raise ValueError("is_training=False needs moving_mean and moving_var")
+    B, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    vecs = [t.detach().contiguous() for t in (gamma, beta, moving_mean, moving_var)]
+    if any(tuple(t.shape) != (Cout,) or t.dtype != torch.float32 or t.device != x.device for t in vecs):
+        raise ValueError(f"gamma, beta, moving_mean, moving_var must be fp32 [{Cout}] on the device of x")
+    with torch.cuda.device(x.device), torch.no_grad():
+        ws = _workspace(B, H, W, Cin, Cout, x.device)
+        out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+        call("sfm_aspp_conv3x3_bn_act_infer", ptr(x), ptr(w), ptr(vecs[0]), ptr(vecs[1]), ptr(vecs[2]), ptr(vecs[3]),
+             float(epsilon), int(activation), B, H, W, Cin, Cout, int(rate), ptr(out), ptr(ws), stream_of(x))
+    return out
 
 
 class _Conv1x1(torch.autograd.Function):

@@ -48,31 +48,48 @@ __device__ __forceinline__ void mma_step(const float* __restrict__ As, const flo
   }
 }
 
+// Optional per-output-channel epilogue of the forward convolution, applied where the finished sum is stored (the MFMA
+// kernel's store loop, or the slab reduction when the taps are split): y = act(x * scale[c] + shift[c]) - batch norm in
+// INFERENCE mode folded to one FMA (scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean * scale) and ELU.
+// scale == nullptr: none.  (Training-mode batch norm needs the statistics of the whole output first: csrc/bn_elu.hip.)
+struct Epilogue {
+  const float* scale;
+  const float* shift;
+  int act;
+};
+__device__ __forceinline__ float ep_apply(float v, float sc, float sh, int act) {
+  const float z = v * sc + sh;
+  return (act && z <= 0.0f) ? expf(z) - 1.0f : z;
+}
+
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 template <int TM, int TN>
 __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], float* __restrict__ out, long ld, long row0,
-                                          long rows, int col0) {
+                                          long rows, int col0, const Epilogue ep = Epilogue{nullptr, nullptr, 0}) {
   const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      const int col = col0 + j * 32 + c;
+      const float sc = ep.scale ? ep.scale[col] : 1.0f, sh = ep.scale ? ep.shift[col] : 0.0f;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const long row = row0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (row < rows) out[row * ld + col0 + j * 32 + c] = acc[i][j][reg];
+        if (row < rows) out[row * ld + col] = ep.scale ? ep_apply(acc[i][j][reg], sc, sh, ep.act) : acc[i][j][reg];
       }
+    }
 }
 
 // ------------------------------------------------------------------ forward / backward data
 // grid (ceil(M / BM), Cout / BN, splits); a split covers taps [z * tps, (z + 1) * tps) and writes
 // its own slab out + z * split_stride.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool EP>  // EP: apply the epilogue (its own instantiation: the plain kernel stays as it was)
 // waves_per_eu(2, 3): without the upper bound hipcc caps the 128x128 configuration at 128 VGPRs (4 waves per
 // SIMD) and spills the prefetch registers to scratch inside the K loop
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(2, 3))) void aspp_conv_kernel(
     const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out, int B, int H, int W, int Cin,
-    int Cout, int rate, int tps, long split_stride) {
+    int Cout, int rate, int tps, long split_stride, Epilogue ep) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int LDA = BM + 1, LDB = BN + 4;
   constexpr int A_IT = BM * BK / 4 / NT, B_IT = BK * BN / 4 / NT;
@@ -154,7 +171,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     mma_step<TM, TN>(As, Bs, LDA, LDB, wm0, wn0, acc);
     __syncthreads();
   }
-  store_acc<TM, TN>(acc, out + blockIdx.z * split_stride, Cout, m0 + wm0, M, n0 + wn0);
+  if constexpr (EP)
+    store_acc<TM, TN>(acc, out, Cout, m0 + wm0, M, n0 + wn0, ep);  // only launched with gridDim.z == 1
+  else
+    store_acc<TM, TN>(acc, out + blockIdx.z * split_stride, Cout, m0 + wm0, M, n0 + wn0);
 }
 
 // ------------------------------------------------------------------ backward weight
@@ -355,8 +375,16 @@ __global__ __launch_bounds__(192, 2) void aspp_wgrad9_kernel(const float* __rest
 
 // out[e] = sum_z part[z][e] in a fixed order: a workgroup owns 16 float4 outputs, 16 thread groups
 // each add every 16th slab (independent loads in flight), LDS combines the groups in group order.
+__device__ __forceinline__ float4 ep_apply4(float4 s, long e, int Cout, const Epilogue ep) {
+  if (!ep.scale) return s;
+  const int c = (int)((e * 4) % Cout);  // Cout is a multiple of 4: the four lanes of a float4 are channels c .. c + 3
+  const float4 sc = *reinterpret_cast<const float4*>(ep.scale + c), sh = *reinterpret_cast<const float4*>(ep.shift + c);
+  return make_float4(ep_apply(s.x, sc.x, sh.x, ep.act), ep_apply(s.y, sc.y, sh.y, ep.act), ep_apply(s.z, sc.z, sh.z, ep.act),
+                     ep_apply(s.w, sc.w, sh.w, ep.act));
+}
+
 __global__ __launch_bounds__(kBlock) void aspp_reduce_kernel(const float* __restrict__ part, long n4, int splits,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int Cout, Epilogue ep) {
   __shared__ float4 red[16][16];
   const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
   const long e = (long)blockIdx.x * 16 + o;
@@ -373,13 +401,13 @@ __global__ __launch_bounds__(kBlock) void aspp_reduce_kernel(const float* __rest
       const float4 v = red[k][o];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    reinterpret_cast<float4*>(out)[e] = s;
+    reinterpret_cast<float4*>(out)[e] = ep_apply4(s, e, Cout, ep);
   }
 }
 
 // the same for a handful of slabs: one thread per float4, slabs in order
 __global__ __launch_bounds__(kBlock) void aspp_reduce_few_kernel(const float* __restrict__ part, long n4, int splits,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, int Cout, Epilogue ep) {
   const long e = (long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= n4) return;
   float4 s = reinterpret_cast<const float4*>(part)[e];
@@ -387,15 +415,17 @@ __global__ __launch_bounds__(kBlock) void aspp_reduce_few_kernel(const float* __
     const float4 v = reinterpret_cast<const float4*>(part)[(long)z * n4 + e];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  reinterpret_cast<float4*>(out)[e] = s;
+  reinterpret_cast<float4*>(out)[e] = ep_apply4(s, e, Cout, ep);
 }
 
-static void launch_reduce(const float* part, long n4, int splits, float* out, hipStream_t stream) {
+static void launch_reduce(const float* part, long n4, int splits, float* out, hipStream_t stream, int Cout = 4,
+                          Epilogue ep = Epilogue{nullptr, nullptr, 0}) {
   if (splits <= 16)
     hipLaunchKernelGGL(aspp_reduce_few_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, part, n4,
-                       splits, out);
+                       splits, out, Cout, ep);
   else
-    hipLaunchKernelGGL(aspp_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(kBlock), 0, stream, part, n4, splits, out);
+    hipLaunchKernelGGL(aspp_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(kBlock), 0, stream, part, n4, splits, out,
+                       Cout, ep);
 }
 
 // wt[t][co][ci] = w[8 - t][ci][co]: the backward-data problem as a forward convolution
@@ -480,27 +510,46 @@ static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
 // ntaps = 9: the dilated 3x3; ntaps = 1: a 1x1 convolution = the same kernels on the centre tap alone (rate 0 makes every
 // tap offset zero, the weights are [1][Cin][Cout]).
 static int launch_conv(const float* in, const float* wt, float* out, float* slabs, int B, int H, int W, int Cin, int Cout,
-                       int rate, hipStream_t stream, int ntaps = 9) {
+                       int rate, hipStream_t stream, int ntaps = 9, Epilogue ep = Epilogue{nullptr, nullptr, 0}) {
   const long M = (long)B * H * W;
   ConvPlan p = conv_plan(M, Cin, Cout);
   if (ntaps == 1) { p.splits = 1; p.tps = 1; rate = 0; }
   float* dst = p.splits > 1 ? slabs : out;
   const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), Cout / p.bn, p.splits);
   const long stride = M * Cout;
+  const Epilogue kep = p.splits > 1 ? Epilogue{nullptr, nullptr, 0} : ep;  // split taps: the slab reduction applies it
+#define SFM_CONV_LAUNCH(...)                                                                                            \
+  do {                                                                                                                  \
+    if (kep.scale)                                                                                                      \
+      hipLaunchKernelGGL((aspp_conv_kernel<__VA_ARGS__, true>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, \
+                         rate, p.tps, stride, kep);                                                                     \
+    else                                                                                                                \
+      hipLaunchKernelGGL((aspp_conv_kernel<__VA_ARGS__, false>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin,  \
+                         Cout, rate, p.tps, stride, kep);                                                               \
+  } while (0)
   if (p.cfg == 0)
-    hipLaunchKernelGGL((aspp_conv_kernel<128, 128, 64, 64>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, rate,
-                       p.tps, stride);
+    SFM_CONV_LAUNCH(128, 128, 64, 64);
   else if (p.cfg == 1)
-    hipLaunchKernelGGL((aspp_conv_kernel<256, 64, 64, 64>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, rate,
-                       p.tps, stride);
+    SFM_CONV_LAUNCH(256, 64, 64, 64);
   else
-    hipLaunchKernelGGL((aspp_conv_kernel<256, 32, 64, 32>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, rate,
-                       p.tps, stride);
+    SFM_CONV_LAUNCH(256, 32, 64, 32);
+#undef SFM_CONV_LAUNCH
   if (p.splits > 1) {
     const long n4 = stride / 4;
-    launch_reduce(slabs, n4, p.splits, out, stream);
+    launch_reduce(slabs, n4, p.splits, out, stream, Cout, ep);
   }
   return sfm_last_error();
+}
+
+// scale / shift of inference-mode batch norm, one thread per channel
+__global__ void aspp_bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ mean, const float* __restrict__ var, float eps, int C,
+                                    float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = (gamma ? gamma[c] : 1.0f) * (1.0f / sqrtf(var[c] + eps));
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.0f) - mean[c] * sc;
 }
 
 }  // namespace
@@ -522,7 +571,8 @@ extern "C" long long sfm_aspp_conv3x3_workspace_floats(int B, int H, int W, int 
   const long wg = (long)(g.splits > g2.splits ? g.splits : g2.splits) * 9 * Cin * Cout;  // either weight-gradient kernel
   long n = fwd > bwd ? fwd : bwd;
   if (wg > n) n = wg;
-  return n + 4;
+  n = (n + 3) & ~3L;
+  return n + 2L * Cout + 4;  // + the folded scale / shift of sfm_aspp_conv3x3_bn_act_infer, 16-byte aligned
 }
 
 // slim.conv2d(in, Cout, [3, 3], rate=rate) without its normaliser / activation (nets.py:457):
@@ -531,6 +581,23 @@ extern "C" int sfm_aspp_conv3x3_fwd(const float* in, const float* w, int B, int 
                                     float* out, float* ws, void* stream) {
   if (!in || !w || !out || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
   return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, rate, (hipStream_t)stream);
+}
+
+// slim.conv2d(in, Cout, [3, 3], rate=rate) under the arg-scope with is_training=False (the inference graphs,
+// test_kitti_depth_con.py:19-65): convolution, batch norm on the MOVING statistics, ELU (act != 0) - one pass, the
+// normalisation and activation applied where the MFMA kernel (or its slab reduction) stores the finished sums.
+extern "C" int sfm_aspp_conv3x3_bn_act_infer(const float* in, const float* w, const float* gamma, const float* beta,
+                                             const float* moving_mean, const float* moving_var, float eps, int act, int B,
+                                             int H, int W, int Cin, int Cout, int rate, float* out, float* ws,
+                                             void* stream_) {
+  if (!in || !w || !moving_mean || !moving_var || !out || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long total = sfm_aspp_conv3x3_workspace_floats(B, H, W, Cin, Cout);
+  float* scale = ws + (total - 4 - 2L * Cout);
+  float* shift = scale + Cout;
+  hipLaunchKernelGGL(aspp_bn_fold_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, gamma, beta, moving_mean, moving_var,
+                     eps, Cout, scale, shift);
+  return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, rate, stream, 9, Epilogue{scale, shift, act});
 }
 
 // dL/d in [B,H,W,Cin] from gout = dL/d out [B,H,W,Cout] (TF autodiff of the same call).

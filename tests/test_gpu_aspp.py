@@ -221,3 +221,23 @@ def test_disp_bottleneck_dense_block(dev, cin, cout, rates, use_skip, use_skip2)
     assert rel_err(yg, yo) <= 2e-5 and rel_err(ug, uo) <= 2e-5
     for a, b in zip(leaves_g, leaves_o):
         assert rel_err(a.grad, b.grad) <= 2e-4
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,rate,act", [
+    (2, 8, 26, 256, 128, 2, True),     # small M: taps split over workgroups, epilogue in the slab reduction
+    (2, 32, 52, 64, 32, 3, True),      # 256x32 tiles, epilogue in the MFMA kernel's store loop
+    (1, 16, 40, 128, 64, 6, False),    # batch norm alone (activation_fn=None)
+])
+def test_conv_bn_elu_inference_epilogue(dev, B, H, W, Cin, Cout, rate, act):
+    """slim.conv2d under is_training=False: batch norm on the moving statistics + ELU fused into the convolution's store"""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / (3 * Cin ** 0.5)
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    mm, mv = torch.randn(Cout, generator=g) * 0.2, torch.rand(Cout, generator=g) + 0.3
+    ref = R.batch_norm_infer(R.dilated_conv3x3(x, w, rate), gamma, beta, mm, mv, 1e-5, act)
+    out = sfm_amd.conv2d_bn_elu(x.to(dev), w.to(dev), gamma.to(dev), beta.to(dev), rate, mm.to(dev), mv.to(dev),
+                                is_training=False, activation=act)
+    assert rel_err(out, ref) <= TOL
+    # the plain convolution next to it is untouched by the epilogue plumbing
+    assert rel_err(sfm_amd.dilated_conv3x3(x.to(dev), w.to(dev), rate), R.dilated_conv3x3(x, w, rate)) <= TOL
