@@ -179,7 +179,8 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
     if (cx_ >= 0 && cx_ < tiles_x && cy_ >= 0 && cy_ < tiles_y)
       tcache[threadIdx.x] = scan_rect(cx_, cy_, stab[cy_ * tiles_x + cx_]);
   }
-  __syncthreads();
+  // (the barrier that publishes acc / tcache sits after the first pixel's loads have been issued: one memory round trip
+  // of the workgroup's start-up less)
 
   const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
   const size_t imgpix = (size_t)b * HW;              // pixel offset of batch item b
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
     }
   };
   fetch(threadIdx.x);
+  __syncthreads();
   for (int k = threadIdx.x; k < n_all; k += kSplatThreads) {
     const int u = nu, v = nv;
     const bool scan = nscan, ok = nok;
