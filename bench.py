@@ -171,6 +171,38 @@ def total_loss_leg(dev, reps: int = 50) -> dict:
             "ms_per_call": ms, "Gpix_per_s": B * H * W * S * N * 2 / (ms * 1e-3) / 1e9, "loss": float(loss.detach())}
 
 
+def config2_leg(dev, reps: int = 10) -> dict:
+    """The per-GPU slice of BASELINE.json configs[2] at 8 GPUs (1248x384, B=32 -> 4 snippets per GPU): same fused step."""
+    from sfm_amd import synth
+    from sfm_amd.loss import LossEngine
+    b2, h2, w2 = 4, 384, 1248
+    inp = synth.to_device(synth.make_inputs(b2, h2, w2, S=S, N=N, seed=synth.SEED), dev)
+    tgt, src, K, pose = inp["tgt"], inp["src"], inp["K"], inp["pose"]
+    depth = torch.stack([d.squeeze(3) for d in inp["depth"]], 0).contiguous()
+    trans = torch.stack(inp["trans"], 0).contiguous()
+    eng = LossEngine(b2, h2, w2, S, N, dev)
+    ne = b2 * h2 * w2 * 3
+
+    def step():
+        p = eng.forward_partials(tgt, src, K, depth, pose, trans, ne, True)
+        return eng.backward(tgt, src, K, depth, pose, trans, p, ne, 1.0, True)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    units = b2 * h2 * w2 * S * N * 2
+    res = {"workload": f"{w2}x{h2} B={b2}/GPU (configs[2]: B=32 over 8 GPUs) S={S} N={N}, same fused step, 1 GPU",
+           "ms_per_step": dt * 1e3, "Gpix_per_s": units / dt / 1e9,
+           "step_frac_of_hbm_peak": 130.0 * units / dt / 1e9 / HBM_PEAK_GBS, "loss": float(out[0])}
+    del eng
+    return res
+
+
 def loader_leg(dev, reps: int = 50) -> dict:
     """decoded uint8 snippets resident in HBM -> tgt / src stack in [-1, 1] + multi-scale
     intrinsics, with the training augmentation (sfm_snippet_unpack: two launches)."""
@@ -332,6 +364,7 @@ def main() -> None:
         if world == 1 and not args.no_aspp:
             line["end_to_end"] = total_loss_leg(dev)
             line["loader"] = loader_leg(dev)
+            line["config2_slice"] = config2_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth.SEED)
         print(json.dumps(line), flush=True)
