@@ -298,9 +298,17 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   SplatWave<GRAD> w;
   const LossDims d = a.d;
   w.d = d;
-  const Item it = split_item(item, a.p.strips, a.p.chunks);
+  // launch order: the N sources of one strip are consecutive waves (same workgroup, same time): `src` is channel-
+  // interleaved over the sources ([.., 3N]), so source i's 12 bytes pull the whole 12N-byte pixel through the caches - with
+  // the sources side by side those lines leave HBM once instead of N times.  The wave's slot in `wavep` keeps the
+  // (scale, source)-major order the reduction sums in.
+  const unsigned un = (unsigned)d.N, uw = (unsigned)item;
+  const int i = (int)(uw % un);
+  Item it = split_item((long)(uw / un), a.p.strips, a.p.chunks);  // it.img = s * B + b here
+  const int b = it.img % d.B, s_ = it.img / d.B;
+  it.img = (s_ * d.N + i) * d.B + b;
+  wavep_out += ((size_t)it.img * a.p.per_img + (size_t)it.chunk * a.p.strips + it.strip) * kWaveTerms;
   const int lane = threadIdx.x & 63;
-  const int b = it.img % d.B, i = (it.img / d.B) % d.N;
   const int HW = d.H * d.W;
   w.C3 = 3 * d.N;
   w.gx = it.strip * kStripOwn - 2 + lane;
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(kBlock) SFM_WPE_GATHER void loss_stencil_gather_ker
 template <bool GRAD>
 __global__ __launch_bounds__(kBlock) SFM_WPE_SPLAT void loss_stencil_splat_kernel(StencilArgs a) {
   const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (w < a.p.n_splat) splat_item<GRAD>(a, w, a.wavep + w * kWaveTerms);
+  if (w < a.p.n_splat) splat_item<GRAD>(a, w, a.wavep);  // the item computes its own slot
 }
 
 }  // namespace
