@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, float
   for (int it = 0; it < kSmoothPerThread; ++it) {
     const unsigned k = (blockIdx.x - a.blk0[m]) * kSmoothPerBlock + it * kBlock + threadIdx.x;
     if (k >= total) break;
-    const unsigned pix = k / C, c = k - pix * C, row = pix / w, x = pix - row * w, y = row % h;
+    const unsigned pix = k / C, row = pix / w, x = pix - row * w, y = row % h;
     const int xi = (int)x, yi = (int)y, wi = (int)w, hi = (int)h;
     // the 13 samples every difference below is made of: row y at x-2..x+2, column x at y-2..y+2 and the
     // four diagonal neighbours; clamped addresses (a clamped sample is never used: see the range tests)
