@@ -240,3 +240,46 @@ def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None
         parts.append(_slim_conv(s2, params, "skip2"))                                    # :466
     xconcat = _slim_conv(torch.cat(parts, dim=3), params, "out", activation=False)       # :470
     return xconcat, upnet
+
+
+# ----------------------------------------------------------------------------- data parallel
+def allreduce_weight_grads(grads, process_group=None, bucket_bytes: int = 32 << 20, average: bool = True):
+    """Sum (or average) the ASPP weight / BN-parameter gradients over the data-parallel ranks in a few large buckets,
+    asynchronously: RCCL over xGMI is a ring of point-to-point links (~150 GB/s each), so a handful of >= 32 MB
+    all-reduces runs at link rate where one call per filter (0.07 ... 19 MB, 11 filters) is latency-bound, and the
+    handles let the caller overlap the exchange with the rest of its backward.
+
+    ``grads``: list of tensors (one device, one dtype), reduced IN PLACE.  Returns a ``wait()`` callable that blocks the
+    current stream until every bucket has landed and the results have been copied back.  With no initialised process
+    group (or one rank) it is a no-op.  Batch norm itself stays per-replica (each rank normalises with its own batch
+    statistics): a declared deviation from the single-device graph, as SURVEY.md 8(e) allows."""
+    import torch.distributed as dist
+    grads = [g for g in grads if g is not None]
+    if not grads or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return lambda: None
+    world = dist.get_world_size(process_group)
+    buckets, cur, size = [], [], 0
+    for g in grads:  # in the order given: the caller lists them in the order its backward produces them
+        nbytes = g.numel() * g.element_size()
+        if cur and size + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(g)
+        size += nbytes
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group, async_op=True), flat, b))
+
+    def wait():
+        for handle, flat, b in pending:
+            handle.wait()
+            if average:
+                flat.div_(world)
+            off = 0
+            for g in b:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+    return wait

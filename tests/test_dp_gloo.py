@@ -77,3 +77,32 @@ def test_single_process_helpers_are_identity():
     p = torch.arange(4, dtype=torch.float64)
     assert torch.equal(L.allreduce_partials(p.clone()), p)
     assert L.global_batch(5) == 5
+
+
+def _grad_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sfm_amd.aspp import allreduce_weight_grads
+        g = torch.Generator().manual_seed(100 + rank)
+        shapes = [(3, 3, 8, 4), (4,), (3, 3, 4, 4), (1, 1, 16, 8), (8,)]   # filters and BN vectors of different sizes
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        mine = [t.clone() for t in grads]
+        wait = allreduce_weight_grads(grads, bucket_bytes=600)              # forces several buckets
+        wait()
+        torch.save({"reduced": grads, "mine": mine}, out_path + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bucketed_weight_gradient_allreduce(tmp_path):
+    """config 5 under data parallelism: the ASPP weight gradients are averaged over the ranks in buckets"""
+    out_path = str(tmp_path / "wg.pt")
+    mp.spawn(_grad_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    r0 = torch.load(out_path + ".0", weights_only=True)
+    r1 = torch.load(out_path + ".1", weights_only=True)
+    for a, b, m0, m1 in zip(r0["reduced"], r1["reduced"], r0["mine"], r1["mine"]):
+        assert torch.equal(a, b)                                   # every rank ends with the same gradients
+        assert torch.allclose(a, (m0 + m1) / 2, rtol=1e-6, atol=1e-7)
