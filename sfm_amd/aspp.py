@@ -18,11 +18,24 @@ from .utils import _check, _same_device
 
 Tensor = torch.Tensor
 _workspaces = {}
+_grad_sinks = {}  # data_ptr of a registered parameter -> (GradBuckets, bucket index, offset, shape)
+
+
+def _grad_out(param: Tensor) -> Tensor:
+    """Where a weight-gradient kernel writes: a fresh view into the parameter's slot of a ``GradBuckets`` if it is
+    registered in one (the gradient is then born inside the flat all-reduce buffer), else a new tensor."""
+    slot = _grad_sinks.get(param.data_ptr())
+    if slot is None:
+        return torch.empty_like(param)
+    buckets, k, off, shape = slot
+    buckets._written[k] = True
+    return buckets.flat[k][off:off + param.numel()].view(shape)
 
 
 def _workspace(B, H, W, Cin, Cout, device) -> Tensor:
     """One scratch buffer per layer shape and device (split-K slabs, flipped weights)."""
-    key = (B, H, W, Cin, Cout, str(device))
+    # per stream as well: calls sharing a workspace must be stream-ordered (include/sfm_amd.h)
+    key = (B, H, W, Cin, Cout, str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
         n = _lib.load().sfm_aspp_conv3x3_workspace_floats(B, H, W, Cin, Cout)
@@ -58,7 +71,7 @@ class _DilatedConv3x3(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 call("sfm_aspp_conv3x3_bwd_data", ptr(gout), ptr(w), B, H, W, Cin, Cout, ctx.rate, ptr(gx), ptr(ws), stream_of(x))
             if ctx.needs_input_grad[1]:
-                gw = torch.empty_like(w)
+                gw = _grad_out(w)
                 call("sfm_aspp_conv3x3_bwd_weight", ptr(x), ptr(gout), B, H, W, Cin, Cout, ctx.rate, ptr(gw), ptr(ws),
                      stream_of(x))
         return gx, gw, None
@@ -98,6 +111,7 @@ class _BatchNormElu(torch.autograd.Function):
             call("sfm_bn_elu_fwd", ptr(x), ptr(gamma), ptr(beta), M, C, float(epsilon), float(decay), int(act), ptr(moving_mean),
                  ptr(moving_var), ptr(y), ptr(mean), ptr(invstd), ptr(ws), stream_of(x))
         ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.beta_ref = beta if beta.data_ptr() in _grad_sinks else None  # only to find its slot in a GradBuckets
         ctx.act = int(act)
         ctx.mark_non_differentiable(mean, invstd)
         return y, mean, invstd
@@ -111,8 +125,8 @@ class _BatchNormElu(torch.autograd.Function):
         with torch.cuda.device(x.device):
             ws = torch.empty(_lib.load().sfm_bn_elu_workspace_floats(M, C) // 2 + 1, dtype=torch.float64, device=x.device)
             gx = torch.empty_like(x)
-            ggamma = torch.empty_like(gamma)
-            gbeta = torch.empty_like(gamma)
+            ggamma = _grad_out(gamma)
+            gbeta = _grad_out(ctx.beta_ref) if ctx.beta_ref is not None else torch.empty_like(gamma)
             call("sfm_bn_elu_bwd", ptr(x), ptr(y), ptr(gy), ptr(gamma), ptr(mean), ptr(invstd), M, C, ctx.act, ptr(gx), ptr(ggamma),
                  ptr(gbeta), ptr(ws), stream_of(x))
         return gx, ggamma, gbeta, None, None, None, None, None
@@ -190,7 +204,7 @@ class _Conv1x1(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 call("sfm_aspp_conv1x1_bwd_data", ptr(gout), ptr(w), B, H, W, Cin, Cout, ptr(gx), ptr(ws), stream_of(x))
             if ctx.needs_input_grad[1]:
-                gw = torch.empty_like(w)
+                gw = _grad_out(w)
                 call("sfm_aspp_conv1x1_bwd_weight", ptr(x), ptr(gout), B, H, W, Cin, Cout, ptr(gw), ptr(ws), stream_of(x))
         return gx, gw
 
@@ -243,11 +257,74 @@ def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None
 
 
 # ----------------------------------------------------------------------------- data parallel
-def allreduce_weight_grads(grads, process_group=None, bucket_bytes: int = 32 << 20, average: bool = True):
-    """Sum (or average) the ASPP weight / BN-parameter gradients over the data-parallel ranks in a few large buckets,
-    asynchronously: RCCL over xGMI is a ring of point-to-point links (~150 GB/s each), so a handful of >= 32 MB
-    all-reduces runs at link rate where one call per filter (0.07 ... 19 MB, 11 filters) is latency-bound, and the
-    handles let the caller overlap the exchange with the rest of its backward.
+# multi_scale_loss returns the GLOBAL loss on every rank (all its reduce_means divide by the global element count), so
+# each rank's parameter gradient is a partial sum of the global gradient: the reduction over ranks is a SUM, never an
+# average (an average would shrink every ASPP weight / gamma / beta gradient by 1/world against the single-device graph).
+class GradBuckets:
+    """Flat all-reduce buffers the ASPP parameter gradients are written into directly.
+
+    ``params``: the weights / gammas / betas in the order the backward produces their gradients (last layer first).
+    Registered parameters get their gradient from ``dilated_conv3x3`` / ``conv1x1`` / ``batch_norm_elu`` as a view
+    into one of a few >= ``bucket_bytes`` flat buffers (no ``torch.cat`` before and no copy after the collective:
+    that was ~100 MB of extra traffic per step at config 5).  ``allreduce()`` sums the written buckets over the ranks
+    in place, asynchronously, and returns a ``wait()``; ``grad(p)`` is the (reduced) gradient of ``p``.
+    RCCL over xGMI is a ring of point-to-point links (~150 GB/s each): a handful of >= 32 MB all-reduces runs at link
+    rate where one call per filter (0.07 ... 19 MB, 11 filters) is latency-bound."""
+
+    def __init__(self, params, bucket_bytes: int = 32 << 20):
+        params = list(params)
+        if not params:
+            raise ValueError("no parameters")
+        dev, dt = params[0].device, params[0].dtype
+        self.flat, self._slots, self._written = [], {}, []
+        sizes, cur = [], 0
+        layout = []
+        for p in params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("one device and one dtype per GradBuckets")
+            n = (p.numel() + 3) // 4 * 4  # 16-byte aligned slots (float4 stores of the weight-gradient kernels)
+            if cur and (cur + n) * p.element_size() > bucket_bytes:
+                sizes.append(cur)
+                cur = 0
+            layout.append((len(sizes), cur, tuple(p.shape), p))
+            cur += n
+        sizes.append(cur)
+        self.flat = [torch.zeros(n, dtype=dt, device=dev) for n in sizes]
+        self._written = [False] * len(sizes)
+        for k, off, shape, p in layout:
+            self._slots[p.data_ptr()] = (k, off, shape)
+            _grad_sinks[p.data_ptr()] = (self, k, off, shape)
+
+    def grad(self, p: Tensor) -> Tensor:
+        k, off, shape = self._slots[p.data_ptr()]
+        return self.flat[k][off:off + p.numel()].view(shape)
+
+    def release(self) -> None:
+        """Unregister the parameters (their gradients are ordinary tensors again)."""
+        for key in self._slots:
+            if _grad_sinks.get(key, (None,))[0] is self:
+                del _grad_sinks[key]
+
+    def allreduce(self, process_group=None):
+        """Sum every bucket over the data-parallel ranks, in place, asynchronously; returns ``wait()``, which makes
+        the current stream wait for the results.  One rank / no process group: a no-op."""
+        import torch.distributed as dist
+        self._written = [False] * len(self.flat)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+            return lambda: None
+        handles = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=process_group, async_op=True) for f in self.flat]
+
+        def wait():
+            for h in handles:
+                h.wait()
+        return wait
+
+
+def allreduce_weight_grads(grads, process_group=None, bucket_bytes: int = 32 << 20, average: bool = False):
+    """SUM the ASPP weight / BN-parameter gradients over the data-parallel ranks in a few large buckets,
+    asynchronously (for gradients that already exist as separate tensors; ``GradBuckets`` avoids the two copies made
+    here).  The sum is the gradient of the global loss ``multi_scale_loss`` returns (see the note above);
+    ``average=True`` divides by the world size and is only for callers whose loss is a per-rank mean.
 
     ``grads``: list of tensors (one device, one dtype), reduced IN PLACE.  Returns a ``wait()`` callable that blocks the
     current stream until every bucket has landed and the results have been copied back.  With no initialised process

@@ -45,6 +45,12 @@ class LossEngine:
             self.params = torch.empty(N * B, _lib.PARAM_STRIDE, dtype=torch.float32, device=self.device)
             call("sfm_loss_workspace_init", ptr(self.ws), B, H, W, S, N, stream_of(self.ws))
 
+    def reinit(self) -> None:
+        """Re-establish the workspace invariant (Ovf and the overflow flags all zero) after a failed step."""
+        B, H, W, S, N = self.dims
+        with torch.cuda.device(self.device):
+            call("sfm_loss_workspace_init", ptr(self.ws), B, H, W, S, N, stream_of(self.ws))
+
     def overflow_state(self):
         """(number of raised overflow flags - one per (image, 64x32 splat tile) -, max |Ovf|): both 0 between steps
         (test / debug aid)."""
@@ -80,6 +86,25 @@ class LossEngine:
         return loss, d_depth, d_pose, d_trans
 
 
+    # the three extra calls of the overlapped data-parallel step, one method each (the CPU test of the host sequence
+    # replaces them by the oracle: tests/test_dp_gloo.py)
+    def forward_splat(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool, buf: Tensor) -> None:
+        B, H, W, S, N = self.dims
+        st = stream_of(tgt)
+        call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
+        call("sfm_loss_forward_splat", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
+             S, N, int(n_elem_global), int(need_grad), ptr(buf), st)
+
+    def forward_gather(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool, buf: Tensor,
+                       e_sums: Tensor) -> None:
+        B, H, W, S, N = self.dims
+        call("sfm_loss_forward_gather", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H,
+             W, S, N, int(n_elem_global), int(need_grad), ptr(buf), ptr(e_sums), stream_of(tgt))
+
+    def loss_value(self, buf: Tensor, e_sums: Tensor, n_elem_global: int, loss: Tensor) -> None:
+        B, H, W, S, N = self.dims
+        call("sfm_loss_value", ptr(buf), ptr(e_sums), S, N, int(n_elem_global), ptr(loss), stream_of(buf))
+
     def step_dp(self, tgt, src, K, depth, pose, trans, n_elem_global: int, process_group=None, need_grad: bool = True,
                 tail: Optional[Tensor] = None):
         """One data-parallel step with both collectives hidden:
@@ -98,22 +123,19 @@ class LossEngine:
         if n_tail:
             buf[self.n_partials:] = tail
         e_sums = torch.empty(S, dtype=torch.float64, device=self.device)
-        st = stream_of(tgt)
-        call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
-        call("sfm_loss_forward_splat", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
-             S, N, int(n_elem_global), int(need_grad), ptr(buf), st)
+        self.forward_splat(tgt, src, K, depth, pose, trans, n_elem_global, need_grad, buf)
         h1 = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
-        call("sfm_loss_forward_gather", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H,
-             W, S, N, int(n_elem_global), int(need_grad), ptr(buf), ptr(e_sums), st)
+        self.forward_gather(tgt, src, K, depth, pose, trans, n_elem_global, need_grad, buf, e_sums)
         h2 = dist.all_reduce(e_sums, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
         h1.wait()  # the current stream waits for all-reduce #1 (not the host)
         loss, d_depth, d_pose, d_trans = self.backward(tgt, src, K, depth, pose, trans, buf, n_elem_global, 1.0, need_grad)
         h2.wait()
-        call("sfm_loss_value", ptr(buf), ptr(e_sums), S, N, int(n_elem_global), ptr(loss), stream_of(tgt))
+        self.loss_value(buf, e_sums, n_elem_global, loss)
         return loss, d_depth, d_pose, d_trans, (buf[self.n_partials:] if n_tail else None)
 
 
 _engines = {}
+_global_batch_cache = {}
 
 
 def _world_size(process_group=None) -> int:
@@ -124,24 +146,51 @@ def _world_size(process_group=None) -> int:
 
 
 def get_engine(B, H, W, S, N, device) -> LossEngine:
-    key = (B, H, W, S, N, str(device))
+    """The cached workspace of a shape, per device AND per stream: the C ABI wants calls that share a workspace
+    stream-ordered (include/sfm_amd.h), so work enqueued on two streams (train / val, an eager call beside a graph
+    capture) never shares one."""
+    device = torch.device(device)
+    key = (B, H, W, S, N, str(device), torch.cuda.current_stream(device).cuda_stream)
     eng = _engines.get(key)
     if eng is None:
         eng = _engines[key] = LossEngine(B, H, W, S, N, device)
     return eng
 
 
-def global_batch(B_local: int, process_group=None) -> int:
-    """Total number of snippets over all ranks (each rank may hold a different count)."""
+def _evict_engine(eng: LossEngine) -> None:
+    """After a failed call between sfm_loss_forward and sfm_loss_backward the overflow accumulator and its flags may be
+    dirty (the invariant of sfm_loss_workspace_init): drop the engine, the next step builds a clean one."""
+    for k, v in list(_engines.items()):
+        if v is eng:
+            del _engines[k]
+
+
+def global_batch(B_local: int, process_group=None, device=None) -> int:
+    """Total number of snippets over all ranks (each rank may hold a different count).
+
+    One all-reduce and ONE host synchronisation (``.item()``) the first time a (process group, local count) pair is
+    seen; the answer is cached after that, so a training loop pays it once, not per step.  The cache assumes a fixed
+    sharding: if the local counts change from step to step differently on different ranks, pass ``global_batch_size``
+    to ``multi_scale_loss`` instead (a rank that hits the cache while another misses it would skip the collective).
+    ``device``: where the exchanged scalar lives for an RCCL group - the device of the caller's tensors, not the
+    process's current device."""
     import torch.distributed as dist
-    if process_group is None and not (dist.is_available() and dist.is_initialized()):
+    if not (dist.is_available() and dist.is_initialized()):
         return B_local
-    t = torch.tensor([B_local], dtype=torch.int64)
-    backend = dist.get_backend(process_group)
-    if backend == "nccl":
-        t = t.cuda()
-    dist.all_reduce(t, group=process_group)
-    return int(t.item())
+    if dist.get_world_size(process_group) == 1:
+        return B_local
+    key = (id(process_group) if process_group is not None else None, int(B_local))
+    gb = _global_batch_cache.get(key)
+    if gb is None:
+        backend = dist.get_backend(process_group)
+        if backend == "nccl":
+            dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+            t = torch.tensor([B_local], dtype=torch.int64, device=dev)
+        else:
+            t = torch.tensor([B_local], dtype=torch.int64)
+        dist.all_reduce(t, group=process_group)
+        gb = _global_batch_cache[key] = int(t.item())
+    return gb
 
 
 def allreduce_partials(partials: Tensor, process_group=None) -> Tensor:
@@ -162,16 +211,18 @@ class _FusedTotalLoss(torch.autograd.Function):
     gradients are computed with the value and scaled by the upstream scalar in ``backward``."""
 
     @staticmethod
-    def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, overlap, poses,
-                *maps):
+    def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, overlap, engine,
+                poses, *maps):
         S = n_scales
         pred_depth, pred_exp = list(maps[:S]), list(maps[S:2 * S])
         pred_disp = list(maps[2 * S:3 * S])
         B, H, W, _ = tgt.shape
         N = poses.shape[1]
-        need = any(ctx.needs_input_grad[9:])
+        need = any(ctx.needs_input_grad[10:])
         with torch.cuda.device(tgt.device):
-            eng = get_engine(B, H, W, S, N, tgt.device)
+            eng = engine if engine is not None else get_engine(B, H, W, S, N, tgt.device)
+            if eng.dims != (B, H, W, S, N) or eng.device != tgt.device:
+                raise ValueError(f"engine was built for {eng.dims} on {eng.device}, got {(B, H, W, S, N)} on {tgt.device}")
             depth = P.pyramid_upsample(pred_depth, H, W).view(S, B, H, W)
             trans = P.pyramid_upsample(pred_exp, H, W)
             n_elem = global_b * H * W * 3
@@ -179,23 +230,30 @@ class _FusedTotalLoss(torch.autograd.Function):
             if smooth_weight > 0:
                 ws_, wa_ = P.smooth_weights(S, smooth_weight, explain_reg_weight)
                 sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need)
-            if overlap and _world_size(process_group) > 1:
-                # data parallel, collectives hidden: the splat-side sums and this rank's share of the regulariser
-                # travel in the first all-reduce (under the gather-side stencil), the min-reprojection sums in a
-                # second one (under the backward)
-                loss, d_depth, d_pose, d_trans, tail = eng.step_dp(tgt, src, K, depth, poses, trans, n_elem, process_group,
-                                                                   need, None if sm is None else sm.double().reshape(1))
-                total = loss if tail is None else loss + tail[0].float()
-            else:
-                # one buffer, ONE all-reduce: the S*(3N+1) partial sums and this rank's share of the regulariser
-                buf = torch.zeros(eng.n_partials + 1, dtype=torch.float64, device=tgt.device)
-                if sm is not None:
-                    buf[-1] = sm
-                eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf[:-1])
-                if global_b != B or process_group is not None:
-                    allreduce_partials(buf, process_group)
-                loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf[:-1], n_elem, 1.0, need)
-                total = loss if sm is None else loss + buf[-1].float()
+            try:
+                if overlap and _world_size(process_group) > 1:
+                    # data parallel, collectives hidden: the splat-side sums and this rank's share of the regulariser
+                    # travel in the first all-reduce (under the gather-side stencil), the min-reprojection sums in a
+                    # second one (under the backward)
+                    loss, d_depth, d_pose, d_trans, tail = eng.step_dp(tgt, src, K, depth, poses, trans, n_elem, process_group,
+                                                                       need, None if sm is None else sm.double().reshape(1))
+                    total = loss if tail is None else loss + tail[0].float()
+                else:
+                    # one buffer, ONE all-reduce: the S*(3N+1) partial sums and this rank's share of the regulariser
+                    buf = torch.zeros(eng.n_partials + 1, dtype=torch.float64, device=tgt.device)
+                    if sm is not None:
+                        buf[-1] = sm
+                    eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf[:-1])
+                    if global_b != B or process_group is not None:
+                        allreduce_partials(buf, process_group)
+                    loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf[:-1], n_elem, 1.0, need)
+                    total = loss if sm is None else loss + buf[-1].float()
+            except Exception:
+                # a failure between the two halves (rejected argument, failed collective) can leave the splat's overflow
+                # accumulator and flags raised: restore the invariant and do not reuse this workspace
+                eng.reinit()
+                _evict_engine(eng)
+                raise
             if need:
                 g_depth = P.pyramid_upsample_grad(d_depth.view(S, B, H, W, 1), [(m.shape[1], m.shape[2]) for m in pred_depth])
                 # the regulariser's gradient of the translation maps is already in place: the adjoint adds to it
@@ -207,14 +265,15 @@ class _FusedTotalLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None,) * 9 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
+        return (None,) * 10 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 
 def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor,
                      pred_depth: Sequence[Tensor], pred_poses: Tensor, pred_exp_logits: Sequence[Tensor],
                      pred_disp: Optional[Sequence[Tensor]] = None, smooth_weight: float = 0.0,
                      explain_reg_weight: float = 0.01, fused: bool = True, process_group=None,
-                     global_batch_size: Optional[int] = None, overlap_collectives: bool = False) -> Tensor:
+                     global_batch_size: Optional[int] = None, overlap_collectives: bool = False,
+                     engine: Optional[LossEngine] = None) -> Tensor:
     """total_loss of SfMLearner_uni.py:75-176 (exp_loss is identically 0 there).
 
     tgt_image [B,H,W,3], src_image_stack [B,H,W,3N] in [-1,1]; intrinsics [B,3,3]
@@ -223,7 +282,10 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
     ``len(pred_depth)`` scales (quirk 1).  Under data parallelism pass the process
     group (or have torch.distributed initialised) and the loss is the global one:
     one stream-ordered all-reduce per step, or with ``overlap_collectives`` two hidden ones
-    (``LossEngine.step_dp``: ~46 us of extra launches and stream hand-offs, so only for slow fabrics)."""
+    (``LossEngine.step_dp``: ~46 us of extra launches and stream hand-offs, so only for slow fabrics).
+    ``global_batch_size``: the number of snippets over all ranks; if omitted it is exchanged once per (group, local
+    batch) and cached (``global_batch``: one all-reduce + host sync the first time).  ``engine``: a ``LossEngine`` to
+    run on instead of the cached one of this shape, device and stream (``GraphedTotalLoss`` owns its own)."""
     if explain_reg_weight <= 0:
         raise NameError("curr_exp_logits is undefined when explain_reg_weight == 0 (SfMLearner_uni.py:127)")
     tgt = U._check(tgt_image, "tgt_image", 4, 3)
@@ -240,11 +302,11 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
     if len(pred_exp_logits) != S:
         raise ValueError("one pred_exp_logits map per scale")
     if fused:
-        gb = global_batch_size if global_batch_size is not None else global_batch(B, process_group)
+        gb = global_batch_size if global_batch_size is not None else global_batch(B, process_group, tgt.device)
         maps = list(pred_depth) + list(pred_exp_logits) + (list(pred_disp) if smooth_weight > 0 else [])
         maps = [U._check(m, "pyramid map", 4) for m in maps]
         return _FusedTotalLoss.apply(tgt, src, K, process_group, gb, float(smooth_weight), float(explain_reg_weight), S,
-                                     bool(overlap_collectives), poses, *maps)
+                                     bool(overlap_collectives), engine, poses, *maps)
     smooth = tgt.new_zeros(())
     if smooth_weight > 0:
         for s in range(S):
@@ -291,14 +353,17 @@ class GraphedTotalLoss:
         self.raw = [t.detach().clone().requires_grad_(True) for t in raw_disp]
         self.exp = [t.detach().clone().requires_grad_(True) for t in pred_exp_logits]
         self.poses = pred_poses.detach().clone().requires_grad_(True)
-        gb = global_batch_size if global_batch_size is not None else global_batch(self.tgt.shape[0], process_group)
+        gb = global_batch_size if global_batch_size is not None else global_batch(self.tgt.shape[0], process_group, dev)
         leaves = self.raw + self.exp + [self.poses]
+        B, H, W, _ = self.tgt.shape
+        # its own workspace: replays must never share Ovf / flags / params with eager calls or other graphs
+        self.engine = LossEngine(B, H, W, len(self.raw), self.poses.shape[1], dev)
 
         def run():
             dn, dp = P.normalize_disp(self.raw)
             loss = multi_scale_loss(self.tgt, self.src, self.K, dp, self.poses, self.exp, pred_disp=dn,
                                     smooth_weight=smooth_weight, explain_reg_weight=explain_reg_weight,
-                                    process_group=process_group, global_batch_size=gb)
+                                    process_group=process_group, global_batch_size=gb, engine=self.engine)
             grads = torch.autograd.grad(loss, leaves)
             return loss, grads
 
