@@ -54,6 +54,22 @@ int sfm_bwd_blocks(int H, int W);
 int sfm_project_coords(const float* depth, const float* trans, const float* params, int B, int H, int W,
                        float* coords, float* z, void* stream);
 
+/* ---- the geometry helpers as stand-alone operators (utils.py exports them; the fused kernels keep the same
+ * arithmetic in registers and never call these).  Forward only, canonical fp32 op order (k-ordered dot products, no
+ * FMA, sin / cos rounded once from fp64, partial-pivot LU inverse).
+ * euler2mat utils.py:27-75: z, y, x [B] (the reference's [B,1]) -> out [B,1,3,3], R = X.Y.Z, angles clipped to +-pi.
+ * pose_vec2mat utils.py:77-96: vec [B,6] = (tx,ty,tz,rx,ry,rz) -> out [B,4,4].
+ * meshgrid utils.py:146-170: out [B, 3 (is_homogeneous) or 2, H, W] = (x, y[, 1]) with the fp32 linspace values.
+ * pixel2cam utils.py:98-122: depth [B,H,W], pixel_coords [B,3,H,W], K [B,3,3], trans [B,H,W,3] or NULL
+ *   (add_trans=False) -> out [B, 4 (is_homogeneous) or 3, H, W]; kinv_ws: scratch of 9*B floats.
+ * cam2pixel utils.py:124-144: cam_coords [B,4,H,W], proj [B,4,4] -> coords [B,H,W,2], z [B,H,W,1]. */
+int sfm_euler2mat(const float* z, const float* y, const float* x, int B, float* out, void* stream);
+int sfm_pose_vec2mat(const float* vec, int B, float* out, void* stream);
+int sfm_meshgrid(int B, int H, int W, int is_homogeneous, float* out, void* stream);
+int sfm_pixel2cam(const float* depth, const float* pixel_coords, const float* K, const float* trans, int B, int H, int W,
+                  int is_homogeneous, float* kinv_ws, float* out, void* stream);
+int sfm_cam2pixel(const float* cam_coords, const float* proj, int B, int H, int W, float* coords, float* z, void* stream);
+
 /* ---- gather direction --------------------------------------------------------------
  * bilinear_sampler utils.py:241-340.  out [B,Ht,Wt,C], mask [B,Ht,Wt,1].
  * idx_dump (may be NULL): int32 [B,Ht,Wt,4] = clipped (x0, x1, y0, y1) of utils.py:286-289. */

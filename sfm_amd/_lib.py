@@ -26,6 +26,11 @@ SIGNATURES = {
     "sfm_pose_setup": [_P, _L, _L, _P, _I, _I, _I, _P, _P],
     "sfm_pose_grad": [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P, _L, _L, _P],
     "sfm_bwd_blocks": [_I, _I],
+    "sfm_euler2mat": [_P, _P, _P, _I, _P, _P],
+    "sfm_pose_vec2mat": [_P, _I, _P, _P],
+    "sfm_meshgrid": [_I, _I, _I, _I, _P, _P],
+    "sfm_pixel2cam": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_cam2pixel": [_P, _P, _I, _I, _I, _P, _P, _P],
     "sfm_project_coords": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "sfm_bilinear_sampler_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sfm_bilinear_sampler_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],

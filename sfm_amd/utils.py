@@ -340,9 +340,34 @@ def corner_indices(imgs_shape, coords):
     return idx
 
 
-def euler2mat(z, y, x):
-    """utils.py:27-75: [B,1] angles -> [B,1,3,3], R = X.Y.Z, angles clipped to +-pi.
-    Small per-batch glue kept in torch device ops; the fused kernels do not call it."""
+class _HipForward(torch.autograd.Function):
+    """Forward = the hand-written kernel (canonical fp32 op order, bit-exact against the oracle); backward = torch
+    autograd of the same formula in torch device ops (``torch_fn``), re-evaluated on the saved inputs.  The fused
+    operators above have hand-written adjoints; these helpers are only per-batch glue for callers that compose the
+    reference's pieces themselves."""
+
+    @staticmethod
+    def forward(ctx, hip_fn, torch_fn, *tensors):
+        ctx.torch_fn = torch_fn
+        ctx.save_for_backward(*tensors)
+        with torch.no_grad():
+            out = hip_fn(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ins = [t.detach().requires_grad_(ctx.needs_input_grad[2 + k]) for k, t in enumerate(ctx.saved_tensors)]
+        with torch.enable_grad():
+            outs = ctx.torch_fn(*ins)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        pairs = [(o, g) for o, g in zip(outs, gouts) if g is not None and o.requires_grad]
+        wanted = [t for t in ins if t.requires_grad]
+        grads = iter(torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True)) if pairs \
+            else iter([None] * len(wanted))
+        return (None, None) + tuple(next(grads) if t.requires_grad else None for t in ins)
+
+
+def _euler2mat_torch(z, y, x):
     bsz = z.shape[0]
     z = torch.clamp(z, -math.pi, math.pi).reshape(bsz)
     y = torch.clamp(y, -math.pi, math.pi).reshape(bsz)
@@ -358,44 +383,126 @@ def euler2mat(z, y, x):
     return torch.matmul(torch.matmul(xmat, ymat), zmat)[:, None]
 
 
-def pose_vec2mat(vec):
-    """utils.py:77-96: [B,6] -> [B,4,4]."""
+def _euler2mat_hip(z, y, x):
+    bsz = z.shape[0]
+    out = torch.empty(bsz, 1, 3, 3, dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        call("sfm_euler2mat", ptr(z), ptr(y), ptr(x), bsz, ptr(out), stream_of(z))
+    return out
+
+
+def euler2mat(z, y, x):
+    """utils.py:27-75: [B,1] angles -> [B,1,3,3], R = X.Y.Z, angles clipped to +-pi (``sfm_euler2mat``)."""
+    z, y, x = (_check(t.reshape(t.shape[0], 1) if isinstance(t, torch.Tensor) and t.dim() == 1 else t, n, 2, 1)
+               for t, n in ((z, "z"), (y, "y"), (x, "x")))
+    if not (z.shape == y.shape == x.shape):
+        raise ValueError("z, y, x must have the same shape [B, 1]")
+    _same_device(z, y, x)
+    return _HipForward.apply(_euler2mat_hip, _euler2mat_torch, z, y, x)
+
+
+def _pose_vec2mat_torch(vec):
     bsz = vec.shape[0]
-    rot = euler2mat(vec[:, 5:6], vec[:, 4:5], vec[:, 3:4]).squeeze(1)
+    rot = _euler2mat_torch(vec[:, 5:6], vec[:, 4:5], vec[:, 3:4]).squeeze(1)
     top = torch.cat([rot, vec[:, 0:3, None]], dim=2)
     filler = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=vec.dtype, device=vec.device).reshape(1, 1, 4).repeat(bsz, 1, 1)
     return torch.cat([top, filler], dim=1)
 
 
+def _pose_vec2mat_hip(vec):
+    out = torch.empty(vec.shape[0], 4, 4, dtype=torch.float32, device=vec.device)
+    with torch.cuda.device(vec.device):
+        call("sfm_pose_vec2mat", ptr(vec), vec.shape[0], ptr(out), stream_of(vec))
+    return out
+
+
+def pose_vec2mat(vec):
+    """utils.py:77-96: [B,6] = (tx,ty,tz,rx,ry,rz) -> [B,4,4] (``sfm_pose_vec2mat``)."""
+    vec = _check(vec, "vec", 2, 6)
+    return _HipForward.apply(_pose_vec2mat_hip, _pose_vec2mat_torch, vec)
+
+
 def meshgrid(batch, height, width, is_homogeneous=True, device=None):
-    """utils.py:146-170 -> [B, 3 (2), H, W] with the reference's fp32 linspace values."""
-    def lin(n):
-        if n == 1:
-            return torch.full((1,), -1.0, dtype=torch.float32, device=device)
-        step = torch.tensor(2.0, dtype=torch.float32) / torch.tensor(float(n - 1), dtype=torch.float32)
-        return -1.0 + step.to(device) * torch.arange(n, dtype=torch.float32, device=device)
-    x_t = ((lin(width) + 1.0) * 0.5 * float(width - 1))[None, :].expand(height, width)
-    y_t = ((lin(height) + 1.0) * 0.5 * float(height - 1))[:, None].expand(height, width)
-    parts = [x_t, y_t] + ([torch.ones_like(x_t)] if is_homogeneous else [])
-    return torch.stack(parts, 0)[None].repeat(batch, 1, 1, 1)
+    """utils.py:146-170 -> [B, 3 (2), H, W] with the reference's fp32 linspace values (``sfm_meshgrid``).
+    ``device`` (not in the reference: TF places the op): the ROCm device, default the current one."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.type != "cuda":
+        raise TypeError(f"meshgrid on {dev}: sfm_amd runs on ROCm devices only (no CPU fallback)")
+    if min(int(batch), int(height), int(width)) < 1:
+        raise ValueError("batch, height and width must be positive")
+    out = torch.empty(batch, 3 if is_homogeneous else 2, height, width, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        call("sfm_meshgrid", int(batch), int(height), int(width), int(bool(is_homogeneous)), ptr(out),
+             stream_of(out))
+    return out
+
+
+def _pixel2cam_torch(is_homogeneous):
+    def fn(depth, pixel_coords, intrinsics, translations=None):
+        batch, height, width = depth.shape
+        cam = torch.matmul(torch.linalg.inv(intrinsics), pixel_coords.reshape(batch, 3, -1)) * depth.reshape(batch, 1, -1)
+        if translations is not None:
+            cam = cam + translations.permute(0, 3, 1, 2).reshape(batch, 3, -1) * cam
+        if is_homogeneous:
+            cam = torch.cat([cam, torch.ones(batch, 1, height * width, dtype=cam.dtype, device=cam.device)], dim=1)
+        return cam.reshape(batch, -1, height, width)
+    return fn
+
+
+def _pixel2cam_hip(is_homogeneous):
+    def fn(depth, pixel_coords, intrinsics, translations=None):
+        batch, height, width = depth.shape
+        out = torch.empty(batch, 4 if is_homogeneous else 3, height, width, dtype=torch.float32, device=depth.device)
+        with torch.cuda.device(depth.device):
+            kinv = torch.empty(batch, 9, dtype=torch.float32, device=depth.device)
+            call("sfm_pixel2cam", ptr(depth), ptr(pixel_coords), ptr(intrinsics), ptr(translations), batch, height, width,
+                 int(is_homogeneous), ptr(kinv), ptr(out), stream_of(depth))
+        return out
+    return fn
 
 
 def pixel2cam(depth, pixel_coords, intrinsics, is_homogeneous=True, add_trans=False, translations=None):
-    """utils.py:98-122 (torch device glue; the fused kernels never materialise this)."""
+    """utils.py:98-122: depth [B,H,W], pixel_coords [B,3,H,W], intrinsics [B,3,3] (, translations [B,H,W,3]) ->
+    camera points [B, 4 (3), H, W] (``sfm_pixel2cam``)."""
+    depth = _check(depth, "depth", 3)
     batch, height, width = depth.shape
-    cam = torch.matmul(torch.linalg.inv(intrinsics), pixel_coords.reshape(batch, 3, -1)) * depth.reshape(batch, 1, -1)
+    pixel_coords = _check(pixel_coords, "pixel_coords", 4)
+    intrinsics = _check(intrinsics, "intrinsics", 3, 3)
+    if tuple(pixel_coords.shape) != (batch, 3, height, width) or tuple(intrinsics.shape) != (batch, 3, 3):
+        raise ValueError("pixel_coords must be [batch, 3, height, width] and intrinsics [batch, 3, 3]")
+    args = [depth, pixel_coords, intrinsics]
     if add_trans:
-        cam = cam + translations.permute(0, 3, 1, 2).reshape(batch, 3, -1) * cam
-    if is_homogeneous:
-        cam = torch.cat([cam, torch.ones(batch, 1, height * width, dtype=cam.dtype, device=cam.device)], dim=1)
-    return cam.reshape(batch, -1, height, width)
+        trans = _check(translations, "translations", 4, 3)
+        if tuple(trans.shape) != (batch, height, width, 3):
+            raise ValueError(f"translations must be {(batch, height, width, 3)}, got {tuple(trans.shape)}")
+        args.append(trans)
+    _same_device(*args)
+    return _HipForward.apply(_pixel2cam_hip(bool(is_homogeneous)), _pixel2cam_torch(bool(is_homogeneous)), *args)
 
 
-def cam2pixel(cam_coords, proj) -> Tuple[Tensor, Tensor]:
-    """utils.py:124-144 -> (coords [B,H,W,2], depth [B,H,W,1])."""
+def _cam2pixel_torch(cam_coords, proj):
     batch, _, height, width = cam_coords.shape
     un = torch.matmul(proj, cam_coords.reshape(batch, 4, -1))
     x_n = un[:, 0:1] / (un[:, 2:3] + 1e-10)
     y_n = un[:, 1:2] / (un[:, 2:3] + 1e-10)
     pix = torch.cat([x_n, y_n], dim=1).reshape(batch, 2, height, width)
     return pix.permute(0, 2, 3, 1), un[:, 2:3].reshape(batch, 1, height, width).permute(0, 2, 3, 1)
+
+
+def _cam2pixel_hip(cam_coords, proj):
+    batch, _, height, width = cam_coords.shape
+    coords = torch.empty(batch, height, width, 2, dtype=torch.float32, device=cam_coords.device)
+    z = torch.empty(batch, height, width, 1, dtype=torch.float32, device=cam_coords.device)
+    with torch.cuda.device(cam_coords.device):
+        call("sfm_cam2pixel", ptr(cam_coords), ptr(proj), batch, height, width, ptr(coords), ptr(z), stream_of(cam_coords))
+    return coords, z
+
+
+def cam2pixel(cam_coords, proj) -> Tuple[Tensor, Tensor]:
+    """utils.py:124-144: cam_coords [B,4,H,W], proj [B,4,4] -> (coords [B,H,W,2], depth [B,H,W,1]) (``sfm_cam2pixel``)."""
+    cam_coords = _check(cam_coords, "cam_coords", 4)
+    proj = _check(proj, "proj", 3, 4)
+    if cam_coords.shape[1] != 4 or tuple(proj.shape) != (cam_coords.shape[0], 4, 4):
+        raise ValueError("cam_coords must be [batch, 4, height, width] and proj [batch, 4, 4]")
+    _same_device(cam_coords, proj)
+    return _HipForward.apply(_cam2pixel_hip, _cam2pixel_torch, cam_coords, proj)

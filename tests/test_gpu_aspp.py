@@ -241,3 +241,39 @@ def test_conv_bn_elu_inference_epilogue(dev, B, H, W, Cin, Cout, rate, act):
     assert rel_err(out, ref) <= TOL
     # the plain convolution next to it is untouched by the epilogue plumbing
     assert rel_err(sfm_amd.dilated_conv3x3(x.to(dev), w.to(dev), rate), R.dilated_conv3x3(x, w, rate)) <= TOL
+
+
+def test_grad_buckets_receive_the_weight_gradients_in_place(dev):
+    """sfm_amd.GradBuckets: the weight-gradient kernels write straight into the flat all-reduce buffers (no cat before /
+    no copy after the collective); the values equal the ordinary gradients bit for bit."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 12, 20, 32, generator=g).to(dev)
+    w3 = (torch.randn(3, 3, 32, 64, generator=g) * 0.05).to(dev).requires_grad_(True)
+    w1 = (torch.randn(1, 1, 64, 32, generator=g) * 0.1).to(dev).requires_grad_(True)
+    gamma = torch.ones(32, device=dev).requires_grad_(True)
+    beta = torch.zeros(32, device=dev).requires_grad_(True)
+
+    def loss():
+        y = sfm_amd.dilated_conv3x3(x, w3, 2)
+        y = sfm_amd.batch_norm_elu(sfm_amd.conv1x1(y, w1), gamma, beta)
+        return (y * y).sum()
+
+    loss().backward()
+    plain = [t.grad.clone() for t in (w3, w1, gamma, beta)]
+    for t in (w3, w1, gamma, beta):
+        t.grad = None
+    gb = sfm_amd.GradBuckets([beta, gamma, w1, w3], bucket_bytes=64 << 10)   # backward order; several buckets
+    try:
+        loss().backward()
+        for t, p in zip((w3, w1, gamma, beta), plain):
+            assert torch.equal(gb.grad(t), p)
+            assert torch.equal(t.grad, p)
+        assert w3.grad.data_ptr() == gb.grad(w3).data_ptr()                    # autograd kept the view: no copy
+        gb.allreduce()()                                                       # one rank: a no-op
+        assert torch.equal(gb.grad(w3), plain[0])
+    finally:
+        gb.release()
+    for t in (w3, w1, gamma, beta):
+        t.grad = None
+    loss().backward()
+    assert w3.grad.data_ptr() != gb.grad(w3).data_ptr()                        # released: ordinary tensors again
