@@ -63,3 +63,35 @@ def to_device(inp: Dict[str, object], device) -> Dict[str, object]:
     for k, v in inp.items():
         out[k] = [t.to(device) for t in v] if isinstance(v, list) else v.to(device)
     return out
+
+
+def make_step_inputs_device(B: int, H: int, W: int, S: int, N: int, seed: int, device, pose_scale: float = 0.01,
+                            cityscapes: bool = False) -> Dict[str, torch.Tensor]:
+    """The tensors one fused step reads, generated ON the device (same distributions as ``make_inputs`` with
+    ``full_res=True``, a device generator - not bit-identical to the CPU stream): for the large benchmark
+    configurations, where CPU generation and the host -> device copy of tens of GB would dominate the run.
+    Returns tgt [B,H,W,3], src [B,H,W,3N], K [B,3,3], pose [B,N,6], depth [S,B,H,W], trans [S,B,H,W,3N] (stacked,
+    the layout sfm_loss_forward reads)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+
+    def smooth(b, c, k):
+        h, w = max(H // k, 2), max(W // k, 2)
+        z = torch.rand(b, c, h, w, generator=g, device=dev) * 2 - 1
+        z = F.interpolate(z, size=(H, W), mode="bilinear", align_corners=True)
+        return z.permute(0, 2, 3, 1)
+
+    tgt = smooth(B, 3, 4).contiguous()
+    src = torch.empty(B, H, W, 3 * N, device=dev)
+    for i in range(N):
+        src[..., 3 * i:3 * i + 3] = torch.clamp(smooth(B, 3, 4) * 0.5 + tgt * 0.5, -1, 1)
+    pose = (torch.randn(B, N, 6, generator=g, device=dev) * pose_scale).contiguous()
+    depth = torch.empty(S, B, H, W, device=dev)
+    trans = torch.empty(S, B, H, W, 3 * N, device=dev)
+    for s in range(S):
+        d = 10.0 * torch.sigmoid(smooth(B, 1, 8) * 2.0) + 0.01
+        d = d / d.mean(dim=(1, 2, 3), keepdim=True)
+        depth[s] = (1.0 / d).squeeze(3)
+        for i in range(N):  # per source: the temporaries stay small at 2048x1024
+            trans[s, ..., 3 * i:3 * i + 3] = 0.01 * smooth(B, 3, 8)
+    return dict(tgt=tgt, src=src, K=intrinsics(B, H, W, cityscapes).to(dev), pose=pose, depth=depth, trans=trans)

@@ -38,11 +38,13 @@ def grad_close(a: torch.Tensor, b: torch.Tensor, tol: float = TOL_GRAD, max_outl
     pixels whose min-selection is numerically undecided (``min_select_ambiguous``); they are left out.
     Required on the rest: at most max_outlier_frac of the elements off by more than tol * max|b|, and a
     relative L2 error <= tol over the others.  Returns (ok, message)."""
-    a = a.detach().double().cpu()
-    b = b.detach().double().cpu()
+    if a.device != b.device:
+        a, b = a.cpu(), b.cpu()
+    a = a.detach().double()    # stays on the device when both are there (the full-size cases are GBs)
+    b = b.detach().double()
     scale = max(float(b.abs().max()), 1e-30)
     if exclude is not None:
-        keep = ~exclude.cpu().expand_as(a)
+        keep = ~exclude.to(a.device).expand_as(a)
         excluded = 1.0 - float(keep.double().mean())
         a, b = a[keep], b[keep]
     else:

@@ -1,0 +1,57 @@
+"""bench.py --gpus N must start its own N ranks when no rank environment is present (the driver runs `python bench.py
+--gpus N`), before anything touches a GPU, and rank 0 must print exactly ONE JSON line.  Rehearsed on the CPU (gloo, no
+kernels, no oracle: --rehearse-launcher), both ways the driver may launch it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_lines(text):
+    out = []
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{"):
+            out.append(json.loads(ln))
+    return out
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+@pytest.mark.timeout(300)
+def test_bench_spawns_its_own_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rehearse-launcher"], capture_output=True, text=True, env=_env(), timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3 and lines[0]["rehearsal"] is True
+
+
+@pytest.mark.timeout(300)
+def test_bench_under_torch_distributed_run():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--steps", "2", "--warmup", "0", "--rehearse-launcher"], capture_output=True, text=True, env=_env(),
+                       timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_single_rank_rehearsal_needs_no_process_group():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-launcher", "--steps", "1"],
+                       capture_output=True, text=True, env=_env(), timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_lines(r.stdout)[0]["n_gpus"] == 1

@@ -40,6 +40,8 @@ def _gpu(inp, dev, fused, smooth_weight=0.0):
     (1, 24, 40, 2, 4, 0.02, True),     # seq=5: sources 2,3 only feed the splat terms (quirk 3)
     (2, 20, 36, 2, 3, 0.02, True),     # three sources: the backward's second launch handles a single one
     (1, 128, 416, 4, 2, 0.01, True),   # one KITTI snippet, 4 scales
+    (1, 384, 1248, 1, 2, 0.01, True),  # one full-resolution KITTI snippet (configs[2] image size): beyond one strip chunk
+                                       # per wave, 20 x 12 splat tiles, the longest rows the oracle affords in seconds
 ])
 @pytest.mark.parametrize("fused", [True, False])
 def test_multi_scale_loss(dev, B, H, W, S, N, ps, full, fused):
