@@ -105,6 +105,19 @@ int sfm_splat_warp_bwd(const float* img, const float* depth, const float* trans,
                        const float* acc, const float* gout, int B, int H, int W, int C, float* d_depth,
                        float* d_trans, float* partials, float* d_img, void* stream);
 
+/* The allocation-free variant of sfm_splat_warp_fwd.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * Same arithmetic and kernels; the [B,H,W,C+1] accumulator lives in a 16 MiB device array inside the library
+ * (one copy per GPU, held until the process ends) instead of a caller workspace, so B*H*W*(C+1) must not exceed
+ * sfm_splat_warp_fwd_static_max_floats() = 4 Mi floats (SFM_ERR_TOO_LARGE otherwise).  Forward only: the accumulator
+ * is not handed back, so there is no matching backward (use sfm_splat_warp_fwd / _bwd for training).  The call
+ * allocates nothing (no hipMalloc / hipFree); it must be made with the device of its pointers current (the array's
+ * address is looked up per current device on the first call).  Every call on a GPU shares that GPU's array: calls
+ * that overlap on one GPU (two streams, two threads) race - serialise them. */
+long long sfm_splat_warp_fwd_static_max_floats(void);
+int sfm_splat_warp_fwd_static(const float* img, const float* depth, const float* trans, const float* params, int B,
+                              int H, int W, int C, float* out, float* mask, void* stream);
+
 /* ---- SSIM: tf_ssim utils.py:548-575 (window 504-519), 3 channels ---------------------
  * out = the raw SSIM map `value` of line 572, [B,H,W,3]. */
 int sfm_ssim_fwd(const float* img1, const float* img2, int B, int H, int W, float* out, void* stream);

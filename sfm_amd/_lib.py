@@ -39,6 +39,8 @@ SIGNATURES = {
     "sfm_bilinear_project_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "sfm_bilinear_project_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "sfm_splat_warp_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "sfm_splat_warp_fwd_static_max_floats": [],
+    "sfm_splat_warp_fwd_static": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "sfm_splat_warp_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sfm_ssim_fwd": [_P, _P, _I, _I, _I, _P, _P],
     "sfm_ssim_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
@@ -97,7 +99,7 @@ def load() -> ctypes.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the build is stale
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name.endswith("_workspace_floats") else ctypes.c_int
+            fn.restype = ctypes.c_longlong if name.endswith(("_workspace_floats", "_max_floats")) else ctypes.c_int
         _lib = lib
     return _lib
 

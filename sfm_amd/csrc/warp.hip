@@ -373,6 +373,41 @@ extern "C" int sfm_splat_warp_fwd(const float* img, const float* depth, const fl
   return splat_fwd_common(true, cs, img, B, H, W, C, 1, acc, out, mask, (hipStream_t)stream);
 }
 
+// ---- the allocation-free variant of sfm_splat_warp_fwd (no counterpart in the reference) ----------------------
+// For callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
+// [B,H,W,C+1] accumulator lives in a file-scope device array instead of a caller-provided workspace.  Each GPU the
+// library runs on holds its own copy of the array (at its own address) until the process ends; the host only ever
+// uses the address hipGetSymbolAddress returned for the CURRENT device - never the symbol itself, which in host code
+// is a stand-in, not a device address.
+namespace sfm {
+constexpr size_t kStaticAccFloats = (size_t)4 << 20;  // 16 MiB per GPU: B*H*W*(C+1) <= 4 Mi floats (c2: 1.7 Mi)
+static __device__ __align__(256) float g_static_acc[kStaticAccFloats];
+constexpr int kMaxDevices = 64;
+static float* g_static_acc_ptr[kMaxDevices];  // per device, filled on the first call made with that device current
+}  // namespace sfm
+
+extern "C" long long sfm_splat_warp_fwd_static_max_floats(void) { return (long long)kStaticAccFloats; }
+
+extern "C" int sfm_splat_warp_fwd_static(const float* img, const float* depth, const float* trans, const float* params,
+                                         int B, int H, int W, int C, float* out, float* mask, void* stream) {
+  if (!img || !depth || !params || !out || !mask || !shape_ok(B, H, W, C)) return SFM_ERR_ARG;
+  if ((size_t)B * H * W * (C + 1) > kStaticAccFloats) return SFM_ERR_TOO_LARGE;
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return SFM_ERR_ARG;
+  float* acc = g_static_acc_ptr[dev];
+  if (!acc) {  // once per device, with that device current (racing first calls resolve the same address)
+    e = hipGetSymbolAddress((void**)&acc, HIP_SYMBOL(g_static_acc));
+    if (e != hipSuccess) return (int)e;
+    if (!acc) return SFM_ERR_ARG;
+    g_static_acc_ptr[dev] = acc;
+  }
+  CoordSrc cs{nullptr, nullptr, depth, trans, params, sfm_lin_step(W), sfm_lin_step(H)};
+  // splat_fwd_common clears the part of the array this call uses (the last call's sums are still in it)
+  return splat_fwd_common(true, cs, img, B, H, W, C, 1, acc, out, mask, (hipStream_t)stream);
+}
+
 extern "C" int sfm_bilinear_project_bwd(const float* img, const float* coords, const float* z, const float* acc,
                                         const float* gout, int B, int H, int W, int C, float* d_coords, float* d_z,
                                         float* d_img, void* stream) {

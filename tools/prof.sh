@@ -5,7 +5,7 @@ tag=${1:-x}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out
-timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out.log 2>&1
+timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-aspp > $out.log 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
