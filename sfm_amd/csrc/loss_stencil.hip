@@ -23,8 +23,6 @@
 // the splat normalisation: nothing here feeds an integer pixel index, the tolerance is the
 // loss's 1e-5 / the gradients' 1e-4, and the kernel is VALU-issue bound.
 #include "loss_common.h"
-#include <cstdlib>
-#include <mutex>
 #include <type_traits>
 
 // occupancy targets (waves per SIMD): see the Makefile / DESIGN.md section 5
@@ -508,59 +506,20 @@ __global__ __launch_bounds__(kBlock) SFM_WPE_SPLAT void loss_stencil_splat_kerne
 
 }  // namespace
 
-// The two stencil kernels are independent of each other (the gather side reads G, the splat side Acc) and neither
-// fills the machine alone at small sizes (the gather side is ONE round of 2-waves-per-SIMD workgroups at c2), so when
-// both are wanted they run side by side: the gather side on a second stream of the library, forked from and joined to
-// the caller's stream with events (works under graph capture as well: a captured fork / join).  One side stream and
-// event pair per device, created on first use (SFM_STENCIL_FORK=0 keeps them back to back on the caller's stream).
-namespace {
-struct ForkCtx {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
-  std::mutex mu;  // the record / wait pairs of one call must not interleave with another host thread's
-};
-ForkCtx* fork_ctx() {
-  static ForkCtx ctx[64];
-  static const bool enabled = [] { const char* e = getenv("SFM_STENCIL_FORK"); return !(e && e[0] == '0'); }();
-  if (!enabled) return nullptr;
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  ForkCtx& c = ctx[dev];
-  std::lock_guard<std::mutex> lk(c.mu);
-  if (!c.ok) {
-    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    c.ok = true;
-  }
-  return &c;
-}
-}  // namespace
-
+// Both kernels go to the caller's stream, back to back.  Running them side by side (the gather side on a second stream,
+// forked and joined with events) was measured at c2 and is SLOWER: 116 us for the pair instead of 96 (gather 93 us
+// instead of 43, splat 80 instead of 56; profiles/r02_fork_experiment.txt) - together they want more VALU issue slots
+// and cache than the chip has, so they only get in each other's way.
 int launch_loss_stencil(const StencilArgs& a, bool need_grad, int which, hipStream_t stream) {
   constexpr int WPB = kBlock / 64;
   const dim3 gs((unsigned)((a.p.n_splat + WPB - 1) / WPB)), gg((unsigned)((a.p.n_gather + WPB - 1) / WPB));
   const bool gather = (which & kStencilGather) && a.p.n_gather, splat = (which & kStencilSplat) != 0;
-  ForkCtx* fc = (gather && splat) ? fork_ctx() : nullptr;
-  std::unique_lock<std::mutex> lk;
-  if (fc) lk = std::unique_lock<std::mutex>(fc->mu);
-  hipStream_t gstream = stream;
-  if (fc) {
-    if (hipEventRecord(fc->fork, stream) != hipSuccess || hipStreamWaitEvent(fc->side, fc->fork, 0) != hipSuccess) fc = nullptr;
-    else gstream = fc->side;
-  }
   if (need_grad) {
-    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<true>, gg, dim3(kBlock), 0, gstream, a);
+    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<true>, gg, dim3(kBlock), 0, stream, a);
     if (splat) hipLaunchKernelGGL(loss_stencil_splat_kernel<true>, gs, dim3(kBlock), 0, stream, a);
   } else {
-    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<false>, gg, dim3(kBlock), 0, gstream, a);
+    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<false>, gg, dim3(kBlock), 0, stream, a);
     if (splat) hipLaunchKernelGGL(loss_stencil_splat_kernel<false>, gs, dim3(kBlock), 0, stream, a);
-  }
-  if (fc) {
-    hipError_t e = hipEventRecord(fc->join, fc->side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(stream, fc->join, 0);
-    if (e != hipSuccess) return (int)e;
   }
   return sfm_last_error();
 }
