@@ -175,6 +175,23 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
                       const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
                       float* d_pose, void* stream);
 
+/* The same step fed with the prediction PYRAMID instead of maps already resized to HxW: depth_s[s]
+ * [B,h[s],w[s]] = pred_depth[s], trans_s[s] [B,h[s],w[s],3N] = pred_exp_logits[s] at their native sizes (HOST arrays of S
+ * <= 8 device pointers / sizes, read at call time; h[s] <= H, w[s] <= W).  The kernels evaluate
+ * tf.image.resize_bilinear(..., [H, W]) of SfMLearner_uni.py:91, 113 per pixel while loading (TF-1 defaults, the
+ * arithmetic of sfm_pyramid_upsample_fwd bit for bit; a level at full size is read directly), so the [S,B,H,W,1+3N]
+ * intermediate of sfm_pyramid_upsample_fwd is never written or read.  Everything else - workspace, partials, the
+ * all-reduce between the two calls, loss_out, d_pose - as sfm_loss_forward / sfm_loss_backward.  d_depth [S,B,H,W] and
+ * d_trans [S,B,H,W,3N] are the gradients with respect to the RESIZED maps; sfm_pyramid_upsample_bwd takes them to the
+ * pyramid's sizes. */
+int sfm_loss_forward_pyr(const float* tgt, const float* src, const float* const* depth_s, const float* const* trans_s,
+                         const int* h, const int* w, const float* params, float* ws, int B, int H, int W, int S, int N,
+                         long long n_elem_global, int need_grad, double* partials, void* stream);
+int sfm_loss_backward_pyr(const float* tgt, const float* src, const float* const* depth_s, const float* const* trans_s,
+                          const int* h, const int* w, const float* params, float* ws, int B, int H, int W, int S, int N,
+                          long long n_elem_global, float gloss, int need_grad, const double* partials, const float* pose,
+                          const float* K, float* loss_out, float* d_depth, float* d_trans, float* d_pose, void* stream);
+
 /* ---- the prediction pyramid either side of the warp loop ----------------------
  * All scales of a call go in one launch; the per-scale pointer / size arrays are HOST arrays read at call
  * time (S, n_maps <= 16).  No exchange step: under data parallelism pass the global batch and sum the

@@ -48,6 +48,8 @@ SIGNATURES = {
     "sfm_loss_num_partials": [_I, _I, _I, _I, _I],
     "sfm_loss_workspace_init": [_P, _I, _I, _I, _I, _I, _P],
     "sfm_loss_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
+    "sfm_loss_forward_pyr": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
+    "sfm_loss_backward_pyr": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "sfm_loss_forward_splat": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
     "sfm_loss_forward_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P, _P],
     "sfm_loss_value": [_P, _P, _I, _I, _LL, _P, _P],

@@ -76,14 +76,44 @@ __device__ __forceinline__ int4 scan_rect(int tx, int ty, int4 sft) {
   return make_int4(xl, xl + STW + 2 * sft.z, yl, yl + STH + 2 * sft.w);
 }
 
+// One pixel's depth and per-source translation from the level-s maps of the pyramid: the four taps and weights of
+// tf.image.resize_bilinear (same arithmetic as pyramid_upsample_fwd_kernel, bit for bit).
+struct PyrLevel {
+  const float* d;   // depth_s of this batch item
+  const float* t;   // trans_s of this batch item, already offset to the source's three channels
+  int h, w;
+  float sy, sx;
+  bool lowres;      // false: the level is at HxW and is read directly
+};
+__device__ __forceinline__ PyrLevel pyr_level(const PyrMaps& pm, int s, int b, int i, int C3, int H, int W) {
+  PyrLevel l;
+  l.h = pm.h[s]; l.w = pm.w[s]; l.sy = pm.sy[s]; l.sx = pm.sx[s];
+  l.lowres = !(l.h == H && l.w == W);
+  l.d = pm.depth[s] + (size_t)b * l.h * l.w;
+  l.t = pm.trans[s] + (size_t)b * l.h * l.w * C3 + 3 * i;
+  return l;
+}
+__device__ __forceinline__ void pyr_read(const PyrLevel& l, int C3, int v, int u, float& dep, float& t0, float& t1, float& t2) {
+  const Lerp ly = lerp_of(v, l.sy, l.h), lx = lerp_of(u, l.sx, l.w);
+  const int o00 = ly.lo * l.w + lx.lo, o01 = ly.lo * l.w + lx.hi, o10 = ly.hi * l.w + lx.lo, o11 = ly.hi * l.w + lx.hi;
+  const float d00 = l.d[o00], d01 = l.d[o01], d10 = l.d[o10], d11 = l.d[o11];
+  const f3 a = ld3(l.t + (size_t)o00 * C3), bq = ld3(l.t + (size_t)o01 * C3), c = ld3(l.t + (size_t)o10 * C3),
+           e = ld3(l.t + (size_t)o11 * C3);
+  dep = lerp4(d00, d01, d10, d11, lx.l, ly.l);
+  t0 = lerp4(a.x, bq.x, c.x, e.x, lx.l, ly.l);
+  t1 = lerp4(a.y, bq.y, c.y, e.y, lx.l, ly.l);
+  t2 = lerp4(a.z, bq.z, c.z, e.z, lx.l, ly.l);
+}
+
 // Sixteen lanes per (image, tile), nine of them active: mid-range and half-range of the displacement (x - u, y - v)
 // over a 3x3 grid of sample pixels of the tile -> shift and reach of the tile's scan window.  One sample per lane, so
 // the kernel is one load round trip deep (it ran nine dependent ones when a thread walked the samples); the 16-lane
 // min / max reduction is a shuffle butterfly.  A pixel at u with displacement in [lo, hi] has corners
 // floor(u + dx) + {0, 1}: reach = half-range + 1.5 covers the sampled spread; the additive margin (kReachAdd) covers
 // the variation between samples.  Any table is correct; a good one keeps the overflow rare and the scan small.
+template <bool PYR>
 __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __restrict__ depth,
-                                                                 const float* __restrict__ trans,
+                                                                 const float* __restrict__ trans, PyrMaps pm,
                                                                  const float* __restrict__ params, LossDims d,
                                                                  float step_x, float step_y, int tiles_x, int tiles_y,
                                                                  int4* __restrict__ shift, int radd, int rmin, int rmax) {
@@ -108,9 +138,22 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
     const size_t sb = ((size_t)s * d.B + b) * HW;
     const int u = xa + ((xb - xa) * jx) / 2, v = ya + ((yb - ya) * jy) / 2;
     const int p = v * d.W + u;
-    const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
-    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), depth[sb + p], true, t.x, t.y,
-                            t.z);
+    float dep, t0, t1, t2;
+    bool direct = true;
+    if constexpr (PYR) {
+      const PyrLevel lv = pyr_level(pm, s, b, i, C3, d.H, d.W);
+      direct = !lv.lowres;
+      if (lv.lowres) pyr_read(lv, C3, v, u, dep, t0, t1, t2);
+      else {
+        const f3 t = ld3(lv.t + (size_t)p * C3);
+        dep = lv.d[p]; t0 = t.x; t1 = t.y; t2 = t.z;
+      }
+    } else {
+      const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
+      dep = depth[sb + p]; t0 = t.x; t1 = t.y; t2 = t.z;
+    }
+    (void)direct;
+    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, true, t0, t1, t2);
     // displacement of the clipped landing point (what the corners are clipped to); NaNs drop out of fmin / fmax
     lo_x = hi_x = fminf(fmaxf(g.x, 0.0f), xmax) - (float)u;
     lo_y = hi_y = fminf(fmaxf(g.y, 0.0f), ymax) - (float)v;
@@ -132,10 +175,11 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
 }
 
 // grid: tiles_x * tiles_y * S*N*B blocks (1-D), 256 threads.
+template <bool PYR>
 __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const float* __restrict__ tgt,
                                                                  const float* __restrict__ src,
                                                                  const float* __restrict__ depth,
-                                                                 const float* __restrict__ trans,
+                                                                 const float* __restrict__ trans, PyrMaps pm,
                                                                  const float* __restrict__ params, LossDims d,
                                                                  float step_x, float step_y, int tiles_x, int tiles_y,
                                                                  const int4* __restrict__ shift, float* __restrict__ G,
@@ -212,13 +256,22 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   bool nscan = false, nok = false;
   float ndep = 0.f;
   f3 nt{0.f, 0.f, 0.f}, ntv{0.f, 0.f, 0.f};
+  PyrLevel lv{};
+  if constexpr (PYR) lv = pyr_level(pm, s, b, i, C3, d.H, d.W);
+  const float* __restrict__ dmap = PYR ? lv.d : depth + sb;                       // a full-size level is read directly
+  const float* __restrict__ tmap = PYR ? lv.t : trans + sb * C3 + 3 * i;
+  const bool lowres = PYR && lv.lowres;  // workgroup-uniform
   auto fetch = [&](int k) {
     nok = k < n_all && locate(k, nu, nv, nscan);
     if (nok) {
       const int p = nv * d.W + nu;
-      ndep = depth[sb + p];
-      nt = ld3(trans + (sb + p) * C3 + 3 * i);
       ntv = ld3(tgt + (imgpix + p) * 3);
+      if (lowres) {
+        pyr_read(lv, C3, nv, nu, ndep, nt.x, nt.y, nt.z);
+      } else {
+        ndep = dmap[p];
+        nt = ld3(tmap + (size_t)p * C3);
+      }
     }
   };
   fetch(threadIdx.x);
@@ -412,7 +465,7 @@ __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S,
 // after the first add their share to d_depth (accumulate != 0).
 // GATHERED: these are sources 0, 1, the ones the min-reprojection term gathers (:168); NTC: d.N when known at compile time
 // (the seq = 3 case keeps its compile-time strides: 143 VGPRs instead of 154), else 0
-template <int NL, bool GATHERED, int NTC, int IB>
+template <int NL, bool GATHERED, int NTC, int IB, bool PYR>
 #ifndef SFM_WPE_BWD
 #define SFM_WPE_BWD
 #endif
@@ -423,7 +476,7 @@ __global__ __launch_bounds__(kBlock) SFM_WPE_BWD
 void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                const float* __restrict__ src,
                                                                const float* __restrict__ depth,
-                                                               const float* __restrict__ trans,
+                                                               const float* __restrict__ trans, PyrMaps pm,
                                                                const float* __restrict__ params,
                                                                const float* __restrict__ Hb,
                                                                const float* __restrict__ dG,
@@ -470,14 +523,34 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
   // gathers of a PAIR of sources are all issued before the first of them is consumed.
   float n_dep;
   f3 n_tv, n_t[N];
+  PyrLevel lv{};
+  if constexpr (PYR) lv = pyr_level(pm, s, b, i_base, C3, d.H, d.W);
+  const float* __restrict__ dmap = PYR ? lv.d : depth + sb;                       // a full-size level is read directly
+  const float* __restrict__ tmap = PYR ? lv.t : trans + sb * C3 + 3 * i_base;
+  const bool lowres = PYR && lv.lowres;  // workgroup-uniform
   auto fetch1 = [&](int it) {
     const int k = it * kBlock + threadIdx.x;
     const int u = min(x0 + (k & (BTW - 1)), d.W - 1), v = min(y0 + k / BTW, d.H - 1);  // clamped: always a valid address
     const int p = v * d.W + u;
-    n_dep = depth[sb + p];
     n_tv = ld3(tgt + (img + p) * 3);
+    if (lowres) {
+      const Lerp ly = lerp_of(v, lv.sy, lv.h), lx = lerp_of(u, lv.sx, lv.w);
+      const int o00 = ly.lo * lv.w + lx.lo, o01 = ly.lo * lv.w + lx.hi, o10 = ly.hi * lv.w + lx.lo, o11 = ly.hi * lv.w + lx.hi;
+      n_dep = lerp4(lv.d[o00], lv.d[o01], lv.d[o10], lv.d[o11], lx.l, ly.l);
 #pragma unroll
-    for (int i = 0; i < N; ++i) n_t[i] = ld3(trans + (sb + p) * C3 + 3 * (i_base + i));
+      for (int i = 0; i < N; ++i) {
+        const float* tp = lv.t + 3 * i;
+        const f3 a = ld3(tp + (size_t)o00 * C3), bq = ld3(tp + (size_t)o01 * C3), c = ld3(tp + (size_t)o10 * C3),
+                 e = ld3(tp + (size_t)o11 * C3);
+        n_t[i].x = lerp4(a.x, bq.x, c.x, e.x, lx.l, ly.l);
+        n_t[i].y = lerp4(a.y, bq.y, c.y, e.y, lx.l, ly.l);
+        n_t[i].z = lerp4(a.z, bq.z, c.z, e.z, lx.l, ly.l);
+      }
+    } else {
+      n_dep = dmap[p];
+#pragma unroll
+      for (int i = 0; i < N; ++i) n_t[i] = ld3(tmap + (size_t)p * C3 + 3 * i);
+    }
   };
   fetch1(0);
 #pragma unroll 1
@@ -667,12 +740,15 @@ extern "C" int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, in
 
 // phases of the forward: 1 = tile_shift + both warps + splat-side stencil + its 3N sums per scale,
 // 2 = gather-side stencil + the min-reprojection sum per scale, 3 = everything in the plain order
+// pm: the prediction pyramid the warps read (then depth / trans are unused and may be null), or null = depth / trans
+// are the maps already resized to HxW, stacked over the scales
 static int loss_forward_phases(int phases, const float* tgt, const float* src, const float* depth, const float* trans,
-                               const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
-                               int need_grad, double* partials, double* e_out, void* stream_) {
+                               const PyrMaps* pm, const float* params, float* ws, int B, int H, int W, int S, int N,
+                               long long n_elem_global, int need_grad, double* partials, double* e_out, void* stream_) {
   LossDims d{B, H, W, S, N};
-  if (!tgt || !src || !depth || !trans || !params || !ws || !partials || n_elem_global <= 0 || !dims_ok(d))
+  if (!tgt || !src || (!pm && (!depth || !trans)) || !params || !ws || !partials || n_elem_global <= 0 || !dims_ok(d))
     return SFM_ERR_ARG;
+  const PyrMaps pmv = pm ? *pm : PyrMaps{};
   hipStream_t stream = (hipStream_t)stream_;
   const LossLayout l = loss_layout(d);
   const LossWs& w = l.w;
@@ -682,13 +758,21 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
   if (phases & 1) {
     { StageTimer t(ST_SHIFT, stream);
     const long n = (long)w.n_img * w.stiles_x * w.stiles_y;
-    hipLaunchKernelGGL(loss_tile_shift_kernel, dim3((unsigned)((n * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, depth,
-                       trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift,
-                       kReachAdd, kReachMin, kReachMax); }
+    const dim3 grid((unsigned)((n * 16 + kBlock - 1) / kBlock));
+    if (pm)
+      hipLaunchKernelGGL(loss_tile_shift_kernel<true>, grid, dim3(kBlock), 0, stream, depth, trans, pmv, params, d,
+                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, kReachAdd, kReachMin, kReachMax);
+    else
+      hipLaunchKernelGGL(loss_tile_shift_kernel<false>, grid, dim3(kBlock), 0, stream, depth, trans, pmv, params, d,
+                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, kReachAdd, kReachMin, kReachMax); }
     { StageTimer t(ST_WARP_FWD, stream);
-    hipLaunchKernelGGL(loss_splat_tile_kernel, dim3((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img)), dim3(kSplatThreads), 0,
-                       stream, tgt, src, depth, trans, params, d, sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf,
-                       flags); }
+    const dim3 grid((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img));
+    if (pm)
+      hipLaunchKernelGGL(loss_splat_tile_kernel<true>, grid, dim3(kSplatThreads), 0, stream, tgt, src, depth, trans, pmv, params, d,
+                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf, flags);
+    else
+      hipLaunchKernelGGL(loss_splat_tile_kernel<false>, grid, dim3(kSplatThreads), 0, stream, tgt, src, depth, trans, pmv, params, d,
+                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf, flags); }
     rc = sfm_last_error();
     if (rc) return rc;
   }
@@ -721,8 +805,8 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
 extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
                                 const float* params, float* ws, int B, int H, int W, int S, int N,
                                 long long n_elem_global, int need_grad, double* partials, void* stream_) {
-  return loss_forward_phases(3, tgt, src, depth, trans, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
-                             nullptr, stream_);
+  return loss_forward_phases(3, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, need_grad,
+                             partials, nullptr, stream_);
 }
 
 // The forward in two halves, for a data-parallel step that hides its collectives:
@@ -733,16 +817,16 @@ extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float*
 extern "C" int sfm_loss_forward_splat(const float* tgt, const float* src, const float* depth, const float* trans,
                                       const float* params, float* ws, int B, int H, int W, int S, int N,
                                       long long n_elem_global, int need_grad, double* partials, void* stream_) {
-  return loss_forward_phases(1, tgt, src, depth, trans, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
-                             nullptr, stream_);
+  return loss_forward_phases(1, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, need_grad,
+                             partials, nullptr, stream_);
 }
 
 extern "C" int sfm_loss_forward_gather(const float* tgt, const float* src, const float* depth, const float* trans,
                                        const float* params, float* ws, int B, int H, int W, int S, int N,
                                        long long n_elem_global, int need_grad, double* partials, double* e_sums,
                                        void* stream_) {
-  return loss_forward_phases(2, tgt, src, depth, trans, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
-                             e_sums, stream_);
+  return loss_forward_phases(2, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, need_grad,
+                             partials, e_sums, stream_);
 }
 
 // loss (one float) from the global sums; e_sums (may be NULL): the min-reprojection sums if they were reduced apart
@@ -756,18 +840,18 @@ extern "C" int sfm_loss_value(const double* partials, const double* e_sums, int 
 
 // partials: the (all-reduced) sums of sfm_loss_forward; n_elem_global = B_global*H*W*3 (the value
 // given to sfm_loss_forward).  loss_out: one float.  need_grad = 0 stops after the loss.
-extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float* depth, const float* trans,
-                                 const float* params, float* ws, int B, int H, int W, int S, int N,
-                                 long long n_elem_global, float gloss, int need_grad, const double* partials,
-                                 const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
-                                 float* d_pose, void* stream_) {
+static int loss_backward_common(const float* tgt, const float* src, const float* depth, const float* trans, const PyrMaps* pm,
+                                const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
+                                float gloss, int need_grad, const double* partials, const float* pose, const float* K,
+                                float* loss_out, float* d_depth, float* d_trans, float* d_pose, void* stream_) {
   LossDims d{B, H, W, S, N};
-  if (!tgt || !src || !depth || !trans || !params || !ws || !partials || !loss_out || n_elem_global <= 0 ||
+  if (!tgt || !src || (!pm && (!depth || !trans)) || !params || !ws || !partials || !loss_out || n_elem_global <= 0 ||
       !dims_ok(d))
     return SFM_ERR_ARG;
   if (need_grad && (!pose || !K || !d_depth || !d_trans || !d_pose)) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_layout(d).w;
+  const PyrMaps pmv = pm ? *pm : PyrMaps{};
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   if (!need_grad) {  // forward-only step: the loss, and restore the Ovf / flags invariant here
     { StageTimer t(ST_FINALIZE, stream);
@@ -780,17 +864,22 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   }
   { StageTimer t(ST_WARP_BWD, stream);
   const dim3 grid((unsigned)((long)S * B * w.nblk_bwd));
-#define SFM_LAUNCH_BWD(NSRC, IBASE, NTC)                                                                                 \
-  hipLaunchKernelGGL((loss_warp_bwd_kernel<NSRC, (IBASE) == 0, NTC, IBASE>), grid, dim3(kBlock), 0, stream, tgt, src, depth, trans, params,      \
-                     ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, 1.0 / (double)n_elem_global, gloss,       \
-                     loss_out, d, sfm_lin_step(W),                                                                   \
-                     sfm_lin_step(H), w.btiles_x, w.btiles_y,                                                        \
-                     d_depth, d_trans, ws + w.dPp, ws + w.Ovf, flags)
+#define SFM_LAUNCH_BWD_P(NSRC, IBASE, NTC, PYR)                                                                          \
+  hipLaunchKernelGGL((loss_warp_bwd_kernel<NSRC, (IBASE) == 0, NTC, IBASE, PYR>), grid, dim3(kBlock), 0, stream, tgt, src, depth,  \
+                     trans, pmv, params, ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, 1.0 / (double)n_elem_global,     \
+                     gloss, loss_out, d, sfm_lin_step(W), sfm_lin_step(H), w.btiles_x, w.btiles_y, d_depth, d_trans,       \
+                     ws + w.dPp, ws + w.Ovf, flags)
+#define SFM_LAUNCH_BWD(NSRC, IBASE, NTC)                                   \
+  do {                                                                     \
+    if (pm) SFM_LAUNCH_BWD_P(NSRC, IBASE, NTC, true);                      \
+    else SFM_LAUNCH_BWD_P(NSRC, IBASE, NTC, false);                        \
+  } while (0)
   // sources 0, 1 (the gathered ones); then the rest, two at a time, adding into d_depth
   if (N == 2) SFM_LAUNCH_BWD(2, 0, 2); else SFM_LAUNCH_BWD(2, 0, 0);
   if (N == 3) SFM_LAUNCH_BWD(1, 2, 0);
   if (N == 4) SFM_LAUNCH_BWD(2, 2, 0);
 #undef SFM_LAUNCH_BWD
+#undef SFM_LAUNCH_BWD_P
   }
   int rc = sfm_last_error();
   if (rc) return rc;
@@ -799,6 +888,55 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
   // the last kernel of the step also lowers the overflow flags (Ovf itself was re-zeroed by warp_bwd)
   return sfm_launch_pose_grad(pose, 6L * N, 6L, K, ws + w.dPp, S, w.nblk_bwd, B, N, 0, 1.0f, d_pose, 6L * N, 6L, flags,
                               (int)w.n_flags, stream);
+}
+
+extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float* depth, const float* trans,
+                                 const float* params, float* ws, int B, int H, int W, int S, int N,
+                                 long long n_elem_global, float gloss, int need_grad, const double* partials,
+                                 const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
+                                 float* d_pose, void* stream_) {
+  return loss_backward_common(tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, gloss, need_grad,
+                              partials, pose, K, loss_out, d_depth, d_trans, d_pose, stream_);
+}
+
+// ---- the same step fed with the prediction pyramid -----------------------------------------
+static int fill_pyr_maps(PyrMaps& pm, const float* const* depth_s, const float* const* trans_s, const int* h, const int* w,
+                         int S, int H, int W) {
+  if (!depth_s || !trans_s || !h || !w || S < 1 || S > kMaxScales) return SFM_ERR_ARG;
+  pm = PyrMaps{};
+  for (int s = 0; s < S; ++s) {
+    if (!depth_s[s] || !trans_s[s] || h[s] < 1 || w[s] < 1 || h[s] > H || w[s] > W) return SFM_ERR_ARG;
+    pm.depth[s] = depth_s[s];
+    pm.trans[s] = trans_s[s];
+    pm.h[s] = h[s];
+    pm.w[s] = w[s];
+    pm.sy[s] = (float)h[s] / (float)H;  // CalculateResizeScale: in / static_cast<float>(out)
+    pm.sx[s] = (float)w[s] / (float)W;
+  }
+  return SFM_OK;
+}
+
+extern "C" int sfm_loss_forward_pyr(const float* tgt, const float* src, const float* const* depth_s,
+                                    const float* const* trans_s, const int* h, const int* w, const float* params, float* ws,
+                                    int B, int H, int W, int S, int N, long long n_elem_global, int need_grad,
+                                    double* partials, void* stream_) {
+  PyrMaps pm;
+  const int rc = fill_pyr_maps(pm, depth_s, trans_s, h, w, S, H, W);
+  if (rc) return rc;
+  return loss_forward_phases(3, tgt, src, nullptr, nullptr, &pm, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
+                             nullptr, stream_);
+}
+
+extern "C" int sfm_loss_backward_pyr(const float* tgt, const float* src, const float* const* depth_s,
+                                     const float* const* trans_s, const int* h, const int* w, const float* params, float* ws,
+                                     int B, int H, int W, int S, int N, long long n_elem_global, float gloss, int need_grad,
+                                     const double* partials, const float* pose, const float* K, float* loss_out,
+                                     float* d_depth, float* d_trans, float* d_pose, void* stream_) {
+  PyrMaps pm;
+  const int rc = fill_pyr_maps(pm, depth_s, trans_s, h, w, S, H, W);
+  if (rc) return rc;
+  return loss_backward_common(tgt, src, nullptr, nullptr, &pm, params, ws, B, H, W, S, N, n_elem_global, gloss, need_grad,
+                              partials, pose, K, loss_out, d_depth, d_trans, d_pose, stream_);
 }
 
 // ---- measurement aid (bench.py): per-launch HIP-event timing of the two calls above ----

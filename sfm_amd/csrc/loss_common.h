@@ -13,6 +13,19 @@ struct LossDims {
   int B, H, W, S, N;
 };
 
+// Where the per-pixel inputs of the warps come from when the caller hands over the prediction PYRAMID
+// (pred_depth[s] [B,h_s,w_s], pred_exp_logits[s] [B,h_s,w_s,3N] at their native sizes) instead of maps already resized
+// to HxW: the kernels then evaluate tf.image.resize_bilinear (SfMLearner_uni.py:91, 113) per pixel while loading, with
+// the arithmetic of the stand-alone resize kernels (sfm_device.h lerp_of / lerp4), and the [S,B,H,W,1+3N] intermediate
+// never exists.  A scale at full size is read directly.
+constexpr int kMaxScales = 8;
+struct PyrMaps {
+  const float* depth[kMaxScales];
+  const float* trans[kMaxScales];
+  int h[kMaxScales], w[kMaxScales];
+  float sy[kMaxScales], sx[kMaxScales];  // h / (float)H, w / (float)W (CalculateResizeScale)
+};
+
 // ---- streaming stencil geometry -------------------------------------------------------
 // One wave = one strip of 64 image columns (the outer two on each side are halo: 60 owned)
 // marching down `rows` image rows (+2 halo rows above and below).  No LDS, no barriers.

@@ -142,19 +142,7 @@ __global__ __launch_bounds__(kBlock) void disp_normalize_bwd_kernel(NormArgs a, 
 // tf.image.resize_bilinear, TF-1 defaults (align_corners=False, no half-pixel centres), resize_bilinear_op.cc:
 //   scale = in / (float)out;  src = dst * scale;  lo = floor(src);  hi = min(lo + 1, in - 1);  lerp = src - lo
 //   top = tl + (tr - tl) * xl;  bot = bl + (br - bl) * xl;  out = top + (bot - top) * yl
-struct Lerp {
-  int lo, hi;
-  float l;
-};
-__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_n) {
-  const float src = (float)dst * scale;
-  const float f = floorf(src);
-  Lerp o;
-  o.lo = min((int)f, in_n - 1);
-  o.hi = min(o.lo + 1, in_n - 1);
-  o.l = src - f;
-  return o;
-}
+// (Lerp / lerp_of live in sfm_device.h: the fused loss kernels read the pyramid with the same arithmetic)
 
 // C consecutive floats as the widest chunks whose alignment the NHWC layout guarantees
 template <int C>

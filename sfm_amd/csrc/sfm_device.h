@@ -162,6 +162,30 @@ __device__ __forceinline__ SplatW splat_weights(float x, float y, const Corners&
   return s;
 }
 
+// tf.image.resize_bilinear, TF-1 defaults (align_corners=False, no half-pixel centres), resize_bilinear_op.cc:
+//   scale = in / (float)out;  src = dst * scale;  lo = floor(src);  hi = min(lo + 1, in - 1);  lerp = src - lo
+//   top = tl + (tr - tl) * xl;  bot = bl + (br - bl) * xl;  out = top + (bot - top) * yl
+// Shared by the stand-alone resize kernels (pyramid.hip) and the fused loss kernels that read the prediction pyramid
+// directly (loss.hip): one arithmetic, so the two ways of feeding the warps agree bit for bit.
+struct Lerp {
+  int lo, hi;
+  float l;
+};
+__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_n) {
+  const float src = (float)dst * scale;
+  const float f = floorf(src);
+  Lerp o;
+  o.lo = min((int)f, in_n - 1);
+  o.hi = min(o.lo + 1, in_n - 1);
+  o.l = src - f;
+  return o;
+}
+__device__ __forceinline__ float lerp4(float tl, float tr, float bl, float br, float xl, float yl) {
+  const float top = tl + (tr - tl) * xl;
+  const float bot = bl + (br - bl) * xl;
+  return top + (bot - top) * yl;
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks L and L + 8 share an XCD and its L2;
 // MI355X_MICROARCH.md "Workgroup dispatch").  xcd_contiguous(L, T) renumbers a 1-D grid of T blocks so
 // that each XCD works on one contiguous range of the renumbered ids: neighbouring tiles then share an L2

@@ -28,6 +28,7 @@ from .pyramid import compute_smooth_loss, resize_bilinear  # noqa: F401  (the re
 
 Tensor = torch.Tensor
 ALPHA = 0.15  # SfMLearner_uni.py:84
+MAX_PYR_SCALES = 8  # kMaxScales of csrc/loss_common.h: pointer table of a pyramid call
 
 
 class LossEngine:
@@ -61,28 +62,47 @@ class LossEngine:
         flags = self.ws[-((n_flags + 3) // 4 * 4):].view(torch.int32)[:n_flags]
         return int((flags != 0).sum()), float(ovf.abs().max())
 
+    @staticmethod
+    def _pyr_args(depth, trans):
+        """host arrays of a pyramid call: depth[s] [B,h,w] or [B,h,w,1], trans[s] [B,h,w,3N] at their native sizes"""
+        return (P._ptrs(depth), P._ptrs(trans), P._ints([t.shape[1] for t in trans]), P._ints([t.shape[2] for t in trans]))
+
     def forward_partials(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool = True,
                          out: Optional[Tensor] = None) -> Tensor:
         """First half: both warps, the L1/SSIM stencil and the local partial sums.  ``n_elem_global`` =
-        B_global*H*W*3 (the reduce_mean denominators are global under data parallelism)."""
+        B_global*H*W*3 (the reduce_mean denominators are global under data parallelism).
+        ``depth`` / ``trans``: the maps resized to HxW and stacked ([S,B,H,W], [S,B,H,W,3N]), or LISTS of the
+        pyramid's maps at their native sizes - the kernels then resize while loading (``sfm_loss_forward_pyr``)."""
         B, H, W, S, N = self.dims
         partials = out if out is not None else torch.empty(self.n_partials, dtype=torch.float64, device=self.device)
         st = stream_of(tgt)
         call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
-        call("sfm_loss_forward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W, S,
-             N, int(n_elem_global), int(need_grad), ptr(partials), st)
+        if isinstance(depth, (list, tuple)):
+            call("sfm_loss_forward_pyr", ptr(tgt), ptr(src), *self._pyr_args(depth, trans), ptr(self.params), ptr(self.ws),
+                 B, H, W, S, N, int(n_elem_global), int(need_grad), ptr(partials), st)
+        else:
+            call("sfm_loss_forward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W, S,
+                 N, int(n_elem_global), int(need_grad), ptr(partials), st)
         return partials
 
     def backward(self, tgt, src, K, depth, pose, trans, partials, n_elem_global: int, gloss: float = 1.0,
                  need_grad: bool = True):
+        """Second half.  Returns (loss, d_depth [S,B,H,W], d_pose, d_trans [S,B,H,W,3N]); with pyramid LISTS for
+        ``depth`` / ``trans`` the two gradients are those of the resized maps (``pyramid_upsample_grad`` takes them
+        to the pyramid's sizes)."""
         B, H, W, S, N = self.dims
         loss = torch.empty((), dtype=torch.float32, device=self.device)
-        d_depth = torch.empty_like(depth) if need_grad else None
-        d_trans = torch.empty_like(trans) if need_grad else None
+        d_depth = torch.empty(S, B, H, W, dtype=torch.float32, device=self.device) if need_grad else None
+        d_trans = torch.empty(S, B, H, W, 3 * N, dtype=torch.float32, device=self.device) if need_grad else None
         d_pose = torch.empty_like(pose) if need_grad else None
-        call("sfm_loss_backward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
-             S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), ptr(pose), ptr(K), ptr(loss),
-             ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
+        if isinstance(depth, (list, tuple)):
+            call("sfm_loss_backward_pyr", ptr(tgt), ptr(src), *self._pyr_args(depth, trans), ptr(self.params), ptr(self.ws),
+                 B, H, W, S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), ptr(pose), ptr(K), ptr(loss),
+                 ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
+        else:
+            call("sfm_loss_backward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
+                 S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), ptr(pose), ptr(K), ptr(loss),
+                 ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
         return loss, d_depth, d_pose, d_trans
 
 
@@ -212,19 +232,24 @@ class _FusedTotalLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, overlap, engine,
-                poses, *maps):
+                fuse_resize, poses, *maps):
         S = n_scales
         pred_depth, pred_exp = list(maps[:S]), list(maps[S:2 * S])
         pred_disp = list(maps[2 * S:3 * S])
         B, H, W, _ = tgt.shape
         N = poses.shape[1]
-        need = any(ctx.needs_input_grad[10:])
+        need = any(ctx.needs_input_grad[11:])
         with torch.cuda.device(tgt.device):
             eng = engine if engine is not None else get_engine(B, H, W, S, N, tgt.device)
             if eng.dims != (B, H, W, S, N) or eng.device != tgt.device:
                 raise ValueError(f"engine was built for {eng.dims} on {eng.device}, got {(B, H, W, S, N)} on {tgt.device}")
-            depth = P.pyramid_upsample(pred_depth, H, W).view(S, B, H, W)
-            trans = P.pyramid_upsample(pred_exp, H, W)
+            if fuse_resize and S <= MAX_PYR_SCALES and not (overlap and _world_size(process_group) > 1):
+                # the kernels read the pyramid at its native sizes and resize while loading (SfMLearner_uni.py:91, 113
+                # inside the warps): no [S,B,H,W,1+3N] intermediate
+                depth, trans = pred_depth, pred_exp
+            else:
+                depth = P.pyramid_upsample(pred_depth, H, W).view(S, B, H, W)
+                trans = P.pyramid_upsample(pred_exp, H, W)
             n_elem = global_b * H * W * 3
             g_smooth, sm = None, None
             if smooth_weight > 0:
@@ -265,7 +290,7 @@ class _FusedTotalLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None,) * 10 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
+        return (None,) * 11 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 
 def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor,
@@ -273,7 +298,7 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
                      pred_disp: Optional[Sequence[Tensor]] = None, smooth_weight: float = 0.0,
                      explain_reg_weight: float = 0.01, fused: bool = True, process_group=None,
                      global_batch_size: Optional[int] = None, overlap_collectives: bool = False,
-                     engine: Optional[LossEngine] = None) -> Tensor:
+                     engine: Optional[LossEngine] = None, fuse_resize: bool = True) -> Tensor:
     """total_loss of SfMLearner_uni.py:75-176 (exp_loss is identically 0 there).
 
     tgt_image [B,H,W,3], src_image_stack [B,H,W,3N] in [-1,1]; intrinsics [B,3,3]
@@ -285,7 +310,10 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
     (``LossEngine.step_dp``: ~46 us of extra launches and stream hand-offs, so only for slow fabrics).
     ``global_batch_size``: the number of snippets over all ranks; if omitted it is exchanged once per (group, local
     batch) and cached (``global_batch``: one all-reduce + host sync the first time).  ``engine``: a ``LossEngine`` to
-    run on instead of the cached one of this shape, device and stream (``GraphedTotalLoss`` owns its own)."""
+    run on instead of the cached one of this shape, device and stream (``GraphedTotalLoss`` owns its own).
+    ``fuse_resize`` (fused only): the warp kernels read ``pred_depth`` / ``pred_exp_logits`` at their native sizes and
+    evaluate the ``resize_bilinear`` of :91, 113 while loading; False materialises the resized maps first
+    (``sfm_pyramid_upsample_fwd``) - same numbers bit for bit."""
     if explain_reg_weight <= 0:
         raise NameError("curr_exp_logits is undefined when explain_reg_weight == 0 (SfMLearner_uni.py:127)")
     tgt = U._check(tgt_image, "tgt_image", 4, 3)
@@ -306,7 +334,7 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
         maps = list(pred_depth) + list(pred_exp_logits) + (list(pred_disp) if smooth_weight > 0 else [])
         maps = [U._check(m, "pyramid map", 4) for m in maps]
         return _FusedTotalLoss.apply(tgt, src, K, process_group, gb, float(smooth_weight), float(explain_reg_weight), S,
-                                     bool(overlap_collectives), engine, poses, *maps)
+                                     bool(overlap_collectives), engine, bool(fuse_resize), poses, *maps)
     smooth = tgt.new_zeros(())
     if smooth_weight > 0:
         for s in range(S):

@@ -146,3 +146,59 @@ def test_total_loss_from_raw_network_outputs(dev):
     for s in range(S):
         assert rel_err(rg[s].grad, ro[s].grad) <= TOL_GRAD, f"raw disparity scale {s}"
         assert rel_err(tg[s].grad, to[s].grad) <= TOL_GRAD, f"translations scale {s}"
+
+
+@pytest.mark.parametrize("B,H,W,S,N,sizes", [
+    (2, 32, 64, 4, 2, None),                                   # H >> s: exact halvings
+    (1, 37, 53, 3, 2, [(37, 53), (19, 27), (10, 14)]),          # ragged: no ratio is a power of two
+    (2, 24, 40, 3, 4, [(12, 20), (24, 40), (3, 5)]),            # seq = 5; a full-size level in the middle of the list
+])
+def test_fused_resize_equals_materialised_resize_bit_for_bit(dev, B, H, W, S, N, sizes):
+    """the warp kernels reading the pyramid at its native sizes (sfm_loss_forward_pyr /
+    sfm_loss_backward_pyr: resize_bilinear evaluated while loading) against the same step on maps resized first
+    (sfm_pyramid_upsample_fwd): one arithmetic, so the loss and every gradient must agree bit for bit."""
+    import sfm_amd
+    from sfm_amd import synth
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=71, pose_scale=0.03, full_res=False)
+    g = synth.to_device(inp, dev)
+    if sizes is not None:
+        gen = torch.Generator().manual_seed(72)
+        g["depth"] = [(0.5 + torch.rand(B, h, w, 1, generator=gen)).to(dev) for h, w in sizes]
+        g["trans"] = [(0.02 * torch.randn(B, h, w, 3 * N, generator=gen)).to(dev) for h, w in sizes]
+
+    def run(fuse):
+        depth = [d.detach().clone().requires_grad_(True) for d in g["depth"]]
+        trans = [t.detach().clone().requires_grad_(True) for t in g["trans"]]
+        pose = g["pose"].detach().clone().requires_grad_(True)
+        loss = sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], depth, pose, trans, fuse_resize=fuse)
+        loss.backward()
+        return loss.detach(), [d.grad for d in depth], pose.grad, [t.grad for t in trans]
+
+    la, da, pa, ta = run(True)
+    lb, db, pb, tb = run(False)
+    assert torch.equal(la, lb)
+    assert torch.equal(pa, pb)
+    for s in range(S):
+        assert torch.equal(da[s], db[s]), f"d_depth scale {s}"
+        assert torch.equal(ta[s], tb[s]), f"d_trans scale {s}"
+
+
+def test_pyramid_entry_points_reject_bad_tables(dev):
+    from sfm_amd import _lib
+    from sfm_amd._lib import ptr
+    from sfm_amd.pyramid import _ints, _ptrs
+    lib = _lib.load()
+    B, H, W, S, N = 1, 16, 24, 2, 2
+    t = torch.zeros(B, H, W, 3, device=dev)
+    src = torch.zeros(B, H, W, 6, device=dev)
+    ws = torch.zeros(lib.sfm_loss_workspace_floats(B, H, W, S, N), device=dev)
+    params = torch.zeros(N * B, _lib.PARAM_STRIDE, device=dev)
+    part = torch.zeros(S * (3 * N + 1), dtype=torch.float64, device=dev)
+    d = [torch.ones(B, H, W, device=dev), torch.ones(B, 8, 12, device=dev)]
+    tr = [torch.zeros(B, H, W, 6, device=dev), torch.zeros(B, 8, 12, 6, device=dev)]
+    args = lambda hs, ws_: (ptr(t), ptr(src), _ptrs(d), _ptrs(tr), _ints(hs), _ints(ws_), ptr(params), ptr(ws), B, H, W, S, N,
+                            B * H * W * 3, 0, ptr(part), None)
+    assert lib.sfm_loss_forward_pyr(*args([H, 8], [W, 12])) == 0
+    torch.cuda.synchronize()
+    assert lib.sfm_loss_forward_pyr(*args([H, 2 * H], [W, 12])) == -1       # a level larger than the image
+    assert lib.sfm_loss_forward_pyr(*args([H, 0], [W, 12])) == -1
