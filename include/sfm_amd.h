@@ -181,16 +181,23 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
  * tf.image.resize_bilinear(..., [H, W]) of SfMLearner_uni.py:91, 113 per pixel while loading (TF-1 defaults, the
  * arithmetic of sfm_pyramid_upsample_fwd bit for bit; a level at full size is read directly), so the [S,B,H,W,1+3N]
  * intermediate of sfm_pyramid_upsample_fwd is never written or read.  Everything else - workspace, partials, the
- * all-reduce between the two calls, loss_out, d_pose - as sfm_loss_forward / sfm_loss_backward.  d_depth [S,B,H,W] and
- * d_trans [S,B,H,W,3N] are the gradients with respect to the RESIZED maps; sfm_pyramid_upsample_bwd takes them to the
- * pyramid's sizes. */
+ * all-reduce between the two calls, loss_out, d_pose - as sfm_loss_forward / sfm_loss_backward.
+ * Backward: the adjoint of the resize runs inside the kernel too.  d_depth_s[s] [B,h[s],w[s]] and d_trans_s[s]
+ * [B,h[s],w[s],3N] (host arrays of device pointers) receive the gradients of the pyramid's own maps, ADDED to their
+ * contents: zero-fill them first, or pass maps that already hold another term of the gradient (the regulariser's,
+ * sfm_smooth_loss).  A tile's contributions are summed in LDS and reach a low-resolution map as one global float atomic
+ * per cell and value (cells on tile borders have up to four adders: their last bits depend on the order); no
+ * [S,B,H,W,1+3N] gradient intermediate exists either.  n_extra (0..16): fp64 values stored behind the S*(3N+1) sums
+ * in `partials` - the other terms of total_loss, e.g. the regulariser's share written there by sfm_smooth_loss and
+ * all-reduced with the sums - which are added to loss_out (fp32 adds, as total_loss = pixel_loss + smooth_loss is). */
 int sfm_loss_forward_pyr(const float* tgt, const float* src, const float* const* depth_s, const float* const* trans_s,
                          const int* h, const int* w, const float* params, float* ws, int B, int H, int W, int S, int N,
                          long long n_elem_global, int need_grad, double* partials, void* stream);
 int sfm_loss_backward_pyr(const float* tgt, const float* src, const float* const* depth_s, const float* const* trans_s,
                           const int* h, const int* w, const float* params, float* ws, int B, int H, int W, int S, int N,
-                          long long n_elem_global, float gloss, int need_grad, const double* partials, const float* pose,
-                          const float* K, float* loss_out, float* d_depth, float* d_trans, float* d_pose, void* stream);
+                          long long n_elem_global, float gloss, int need_grad, const double* partials, int n_extra,
+                          const float* pose, const float* K, float* loss_out, float* const* d_depth_s,
+                          float* const* d_trans_s, float* d_pose, void* stream);
 
 /* ---- the prediction pyramid either side of the warp loop ----------------------
  * All scales of a call go in one launch; the per-scale pointer / size arrays are HOST arrays read at call
@@ -234,7 +241,14 @@ int sfm_resize_bilinear_bwd(const float* gout, int B, int h, int w, int C, int H
 long long sfm_smooth_workspace_floats(const int* h, const int* w, const int* c, int n_maps, int B);
 int sfm_smooth_loss(const float* const* maps, float* const* d_maps, const int* h, const int* w, const int* c,
                     const float* w_smooth, const float* w_abs, int n_maps, int B, int B_global, float gscale, float* ws,
-                    float* loss_out, void* stream);
+                    float* loss_out, double* loss_out_f64, void* stream);
+
+/* Upstream-gradient scaling (no counterpart in the reference: TF's autodiff seeds d total_loss = 1).  The fused loss
+ * computes its gradients together with the value; when the caller's autograd later supplies dL/d total_loss as a DEVICE
+ * scalar *g, this rescales the count listed buffers (bufs / n: host arrays, count <= 34) in place from the scale they
+ * currently carry, *cur_scale (a device float the caller initialises to 1), to *g, and stores *g there.  Equal scales
+ * (every plain backward) make it a launch that exits at once. */
+int sfm_scale_grads(float* const* bufs, const long long* n, int count, const float* g, float* cur_scale, void* stream);
 
 /* ---- ASPP dilated 3x3 convolutions: nets.py:451-471 (disp_bottleneck_dense) --------------------
  * slim.conv2d(x, Cout, [3, 3], rate=rate) of nets.py:457, 458, 463 - the convolution itself,

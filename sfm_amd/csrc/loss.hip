@@ -261,13 +261,22 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   const float* __restrict__ dmap = PYR ? lv.d : depth + sb;                       // a full-size level is read directly
   const float* __restrict__ tmap = PYR ? lv.t : trans + sb * C3 + 3 * i;
   const bool lowres = PYR && lv.lowres;  // workgroup-uniform
+  // low-resolution level: the four taps of every map are requested here and interpolated when the pixel is processed
+  // (one iteration later), like the plain loads - the resize must not put a memory round trip back into the loop
+  float pd[4] = {0.f, 0.f, 0.f, 0.f}, pxl = 0.f, pyl = 0.f;
+  f3 pt[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   auto fetch = [&](int k) {
     nok = k < n_all && locate(k, nu, nv, nscan);
     if (nok) {
       const int p = nv * d.W + nu;
       ntv = ld3(tgt + (imgpix + p) * 3);
       if (lowres) {
-        pyr_read(lv, C3, nv, nu, ndep, nt.x, nt.y, nt.z);
+        const Lerp ly = lerp_of(nv, lv.sy, lv.h), lx = lerp_of(nu, lv.sx, lv.w);
+        const int o00 = ly.lo * lv.w + lx.lo, o01 = ly.lo * lv.w + lx.hi, o10 = ly.hi * lv.w + lx.lo, o11 = ly.hi * lv.w + lx.hi;
+        pd[0] = lv.d[o00]; pd[1] = lv.d[o01]; pd[2] = lv.d[o10]; pd[3] = lv.d[o11];
+        pt[0] = ld3(lv.t + (size_t)o00 * C3); pt[1] = ld3(lv.t + (size_t)o01 * C3);
+        pt[2] = ld3(lv.t + (size_t)o10 * C3); pt[3] = ld3(lv.t + (size_t)o11 * C3);
+        pxl = lx.l; pyl = ly.l;
       } else {
         ndep = dmap[p];
         nt = ld3(tmap + (size_t)p * C3);
@@ -279,8 +288,15 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   for (int k = threadIdx.x; k < n_all; k += kSplatThreads) {
     const int u = nu, v = nv;
     const bool scan = nscan, ok = nok;
-    const float dep = ndep;
-    const f3 t = nt, tv = ntv;
+    float dep = ndep;
+    f3 t = nt;
+    const f3 tv = ntv;
+    if (lowres) {
+      dep = lerp4(pd[0], pd[1], pd[2], pd[3], pxl, pyl);
+      t.x = lerp4(pt[0].x, pt[1].x, pt[2].x, pt[3].x, pxl, pyl);
+      t.y = lerp4(pt[0].y, pt[1].y, pt[2].y, pt[3].y, pxl, pyl);
+      t.z = lerp4(pt[0].z, pt[1].z, pt[2].z, pt[3].z, pxl, pyl);
+    }
     fetch(k + kSplatThreads);
     if (!ok) continue;
     const bool home = (u >= x0 && u < x1 && v >= y0 && v < y1);
@@ -448,8 +464,12 @@ __device__ __forceinline__ float loss_value(const double* __restrict__ partials,
 
 // forward-only steps: just the loss (with gradients, the backward warp kernel does this itself)
 __global__ void loss_finalize_kernel(const double* __restrict__ partials, int S, int N, double n_elem,
-                                     float* __restrict__ loss_out, const double* __restrict__ e_sums) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *loss_out = loss_value(partials, S, N, n_elem, e_sums);
+                                     float* __restrict__ loss_out, const double* __restrict__ e_sums, int n_extra) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float l = loss_value(partials, S, N, n_elem, e_sums);
+    for (int k = 0; k < n_extra; ++k) l += (float)partials[S * (3 * N + 1) + k];
+    *loss_out = l;
+  }
 }
 
 // ------------------------------------------------------------------ fused warp backward
@@ -481,8 +501,8 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                const float* __restrict__ Hb,
                                                                const float* __restrict__ dG,
                                                                const double* __restrict__ partials, double n_elem,
-                                                               double inv_n, float gl, float* __restrict__ loss_out,
-                                                               LossDims d,
+                                                               double inv_n, float gl, int n_extra,
+                                                               float* __restrict__ loss_out, LossDims d,
                                                                float step_x, float step_y, int tiles_x, int tiles_y,
                                                                float* __restrict__ d_depth,
                                                                float* __restrict__ d_trans,
@@ -492,6 +512,12 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
   constexpr bool accumulate = IB != 0;
   __shared__ float red[4 * 12];
   constexpr int N = NL;  // sources of this launch
+  // PYR, low-resolution level: the adjoint of the resize (ResizeBilinearGrad: each pixel's gradient goes to the four
+  // cells it was interpolated from, with the forward's own weights) is accumulated per tile in LDS - fp64: ds_add_f64
+  // retires in ~9 cycles where ds_add_f32 takes ~190 - and the tile's footprint is then added to
+  // the level's gradient maps with one global float atomic per cell and value.
+  constexpr int kFootW = BTW + 2, kFootH = BTH + 2, kFootV = 1 + 3 * NL;
+  __shared__ double foot[PYR ? kFootW * kFootH * kFootV : 1];
   const int NT = NTC ? NTC : d.N, C3 = 3 * NT;
   constexpr int NG = 2;  // d.N >= 2 (checked on the host)
   const int ntile = tiles_x * tiles_y;
@@ -503,7 +529,11 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
   const size_t sb = ((size_t)s * d.B + b) * HW;
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);
   // gl = dL/d loss.  The loss itself is one thread's job
-  if (blockIdx.x == 0 && threadIdx.x == 0 && i_base == 0) *loss_out = loss_value(partials, d.S, NT, n_elem);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && i_base == 0) {
+    float l = loss_value(partials, d.S, NT, n_elem);
+    for (int k = 0; k < n_extra; ++k) l += (float)partials[d.S * (3 * NT + 1) + k];  // other terms of total_loss (fp32 adds)
+    *loss_out = l;
+  }
   const size_t hb_plane = (size_t)d.S * NT * d.B * HW * 4;
   Pose ps[N];
   float kv[N], dp[N][12];
@@ -528,6 +558,17 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
   const float* __restrict__ dmap = PYR ? lv.d : depth + sb;                       // a full-size level is read directly
   const float* __restrict__ tmap = PYR ? lv.t : trans + sb * C3 + 3 * i_base;
   const bool lowres = PYR && lv.lowres;  // workgroup-uniform
+  int fx0 = 0, fy0 = 0, fw = 1, fh = 1;  // the tile's footprint on the level: cells [fy0, fy0 + fh) x [fx0, fx0 + fw)
+  if constexpr (PYR) {
+    if (lowres) {
+      fx0 = lerp_of(x0, lv.sx, lv.w).lo;
+      fy0 = lerp_of(y0, lv.sy, lv.h).lo;
+      fw = lerp_of(min(x0 + BTW, d.W) - 1, lv.sx, lv.w).hi - fx0 + 1;
+      fh = lerp_of(min(y0 + BTH, d.H) - 1, lv.sy, lv.h).hi - fy0 + 1;
+      for (int k = threadIdx.x; k < fw * fh * kFootV; k += kBlock) foot[k] = 0.0;
+      __syncthreads();
+    }
+  }
   auto fetch1 = [&](int it) {
     const int k = it * kBlock + threadIdx.x;
     const int u = min(x0 + (k & (BTW - 1)), d.W - 1), v = min(y0 + k / BTW, d.H - 1);  // clamped: always a valid address
@@ -552,17 +593,21 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
       for (int i = 0; i < N; ++i) n_t[i] = ld3(tmap + (size_t)p * C3 + 3 * i);
     }
   };
-  fetch1(0);
+  // (a low-resolution level interpolates 4 + 4N taps per pixel: fetched at the top of the pixel's own iteration, not one
+  // ahead - with the taps of the next pixel in flight beside the gathers of this one the kernel needs 180 VGPRs and
+  // loses its third wave per SIMD; the level's maps are small and stay in L1 / L2)
+  if (!lowres) fetch1(0);
 #pragma unroll 1
   for (int it = 0; it < kLossPPT; ++it) {
     const int k = it * kBlock + threadIdx.x;
     const int u = x0 + (k & (BTW - 1)), v = y0 + k / BTW;
+    if (lowres) fetch1(it);
     const float dep = n_dep;
     const f3 tv = n_tv;
     f3 tr[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) tr[i] = n_t[i];
-    if (it + 1 < kLossPPT) fetch1(it + 1);
+    if (!lowres && it + 1 < kLossPPT) fetch1(it + 1);
     if (u >= d.W || v >= d.H) continue;
     const int p = v * d.W + u;
     const float gxc = grid_coord(u, step_x, xmax), gyc = grid_coord(v, step_y, ymax);
@@ -639,10 +684,52 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
         ddsum += dd_;
       }
     }
-    d_depth[sb + p] = accumulate ? d_depth[sb + p] + ddsum : ddsum;
+    if constexpr (PYR) {
+      if (lowres) {
+        const Lerp ly = lerp_of(v, lv.sy, lv.h), lx = lerp_of(u, lv.sx, lv.w);
+        const float xl = lx.l, yl = ly.l;  // plain locals: a select between struct members is a select between addresses
+        const int cxl = lx.lo - fx0, cxh = lx.hi - fx0, cyl = (ly.lo - fy0) * fw, cyh = (ly.hi - fy0) * fw;
+        // one corner at a time (not unrolled): 7 products live, not 28
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+          const bool qx = (q & 1) != 0, qy = (q & 2) != 0;
+          const float wgt = (qx ? xl : 1.0f - xl) * (qy ? yl : 1.0f - yl);
+          double* f = foot + (size_t)((qy ? cyh : cyl) + (qx ? cxh : cxl)) * kFootV;
+          atomicAdd(f, (double)(wgt * ddsum));
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-      st3(d_trans + (sb + p) * C3 + 3 * (i_base + i), dts[3 * i], dts[3 * i + 1], dts[3 * i + 2]);
+          for (int j = 0; j < 3 * N; ++j) atomicAdd(f + 1 + j, (double)(wgt * dts[j]));
+        }
+      } else {  // a level at full size: one writer per element, added to what the caller put there
+        float* dd = pm.d_depth[s] + (size_t)b * HW + p;
+        *dd = *dd + ddsum;
+        float* dt = pm.d_trans[s] + ((size_t)b * HW + p) * C3 + 3 * i_base;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const f3 o = ld3(dt + 3 * i);
+          st3(dt + 3 * i, o.x + dts[3 * i], o.y + dts[3 * i + 1], o.z + dts[3 * i + 2]);
+        }
+      }
+    } else {
+      d_depth[sb + p] = accumulate ? d_depth[sb + p] + ddsum : ddsum;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        st3(d_trans + (sb + p) * C3 + 3 * (i_base + i), dts[3 * i], dts[3 * i + 1], dts[3 * i + 2]);
+    }
+  }
+  if constexpr (PYR) {
+    if (lowres) {  // the tile's footprint -> the level's gradient maps (cells shared with neighbouring tiles: atomics)
+      __syncthreads();
+      float* gd = pm.d_depth[s] + (size_t)b * lv.h * lv.w;
+      float* gt = pm.d_trans[s] + (size_t)b * lv.h * lv.w * C3 + 3 * i_base;
+      for (int k = threadIdx.x; k < fw * fh * kFootV; k += kBlock) {
+        const int cell = k / kFootV, j = k - cell * kFootV;
+        const int cy = cell / fw, cx = cell - cy * fw;
+        const size_t o = (size_t)(fy0 + cy) * lv.w + (fx0 + cx);
+        const float val = (float)foot[k];
+        if (j == 0) atomicAdd(gd + o, val);
+        else atomicAdd(gt + o * C3 + (j - 1), val);
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -834,7 +921,7 @@ extern "C" int sfm_loss_value(const double* partials, const double* e_sums, int 
                               float* loss_out, void* stream_) {
   if (!partials || !loss_out || S < 1 || N < 2 || N > kMaxSrc || n_elem_global <= 0) return SFM_ERR_ARG;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, partials, S, N, (double)n_elem_global,
-                     loss_out, e_sums);
+                     loss_out, e_sums, 0);
   return sfm_last_error();
 }
 
@@ -842,9 +929,11 @@ extern "C" int sfm_loss_value(const double* partials, const double* e_sums, int 
 // given to sfm_loss_forward).  loss_out: one float.  need_grad = 0 stops after the loss.
 static int loss_backward_common(const float* tgt, const float* src, const float* depth, const float* trans, const PyrMaps* pm,
                                 const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
-                                float gloss, int need_grad, const double* partials, const float* pose, const float* K,
-                                float* loss_out, float* d_depth, float* d_trans, float* d_pose, void* stream_) {
+                                float gloss, int need_grad, const double* partials, int n_extra, const float* pose,
+                                const float* K, float* loss_out, float* d_depth, float* d_trans, float* d_pose,
+                                void* stream_) {
   LossDims d{B, H, W, S, N};
+  if (n_extra < 0 || n_extra > 16) return SFM_ERR_ARG;
   if (!tgt || !src || (!pm && (!depth || !trans)) || !params || !ws || !partials || !loss_out || n_elem_global <= 0 ||
       !dims_ok(d))
     return SFM_ERR_ARG;
@@ -856,7 +945,7 @@ static int loss_backward_common(const float* tgt, const float* src, const float*
   if (!need_grad) {  // forward-only step: the loss, and restore the Ovf / flags invariant here
     { StageTimer t(ST_FINALIZE, stream);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, S, N, (double)n_elem_global, loss_out,
-                       (const double*)nullptr); }
+                       (const double*)nullptr, n_extra); }
     hipLaunchKernelGGL(loss_ovf_clear_kernel, dim3(w.stiles_x * w.stiles_y, w.n_img), dim3(kBlock), 0, stream, ws + w.Ovf, flags,
                        H, W, w.stiles_x);
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_flags * sizeof(int), stream);
@@ -867,7 +956,7 @@ static int loss_backward_common(const float* tgt, const float* src, const float*
 #define SFM_LAUNCH_BWD_P(NSRC, IBASE, NTC, PYR)                                                                          \
   hipLaunchKernelGGL((loss_warp_bwd_kernel<NSRC, (IBASE) == 0, NTC, IBASE, PYR>), grid, dim3(kBlock), 0, stream, tgt, src, depth,  \
                      trans, pmv, params, ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, 1.0 / (double)n_elem_global,     \
-                     gloss, loss_out, d, sfm_lin_step(W), sfm_lin_step(H), w.btiles_x, w.btiles_y, d_depth, d_trans,       \
+                     gloss, n_extra, loss_out, d, sfm_lin_step(W), sfm_lin_step(H), w.btiles_x, w.btiles_y, d_depth, d_trans,       \
                      ws + w.dPp, ws + w.Ovf, flags)
 #define SFM_LAUNCH_BWD(NSRC, IBASE, NTC)                                   \
   do {                                                                     \
@@ -896,12 +985,12 @@ extern "C" int sfm_loss_backward(const float* tgt, const float* src, const float
                                  const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
                                  float* d_pose, void* stream_) {
   return loss_backward_common(tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, gloss, need_grad,
-                              partials, pose, K, loss_out, d_depth, d_trans, d_pose, stream_);
+                              partials, 0, pose, K, loss_out, d_depth, d_trans, d_pose, stream_);
 }
 
 // ---- the same step fed with the prediction pyramid -----------------------------------------
 static int fill_pyr_maps(PyrMaps& pm, const float* const* depth_s, const float* const* trans_s, const int* h, const int* w,
-                         int S, int H, int W) {
+                         int S, int H, int W, float* const* d_depth_s = nullptr, float* const* d_trans_s = nullptr) {
   if (!depth_s || !trans_s || !h || !w || S < 1 || S > kMaxScales) return SFM_ERR_ARG;
   pm = PyrMaps{};
   for (int s = 0; s < S; ++s) {
@@ -912,6 +1001,11 @@ static int fill_pyr_maps(PyrMaps& pm, const float* const* depth_s, const float* 
     pm.w[s] = w[s];
     pm.sy[s] = (float)h[s] / (float)H;  // CalculateResizeScale: in / static_cast<float>(out)
     pm.sx[s] = (float)w[s] / (float)W;
+    if (d_depth_s) {
+      if (!d_trans_s || !d_depth_s[s] || !d_trans_s[s]) return SFM_ERR_ARG;
+      pm.d_depth[s] = d_depth_s[s];
+      pm.d_trans[s] = d_trans_s[s];
+    }
   }
   return SFM_OK;
 }
@@ -930,13 +1024,18 @@ extern "C" int sfm_loss_forward_pyr(const float* tgt, const float* src, const fl
 extern "C" int sfm_loss_backward_pyr(const float* tgt, const float* src, const float* const* depth_s,
                                      const float* const* trans_s, const int* h, const int* w, const float* params, float* ws,
                                      int B, int H, int W, int S, int N, long long n_elem_global, float gloss, int need_grad,
-                                     const double* partials, const float* pose, const float* K, float* loss_out,
-                                     float* d_depth, float* d_trans, float* d_pose, void* stream_) {
+                                     const double* partials, int n_extra, const float* pose, const float* K,
+                                     float* loss_out, float* const* d_depth_s, float* const* d_trans_s, float* d_pose,
+                                     void* stream_) {
   PyrMaps pm;
-  const int rc = fill_pyr_maps(pm, depth_s, trans_s, h, w, S, H, W);
+  const int rc = fill_pyr_maps(pm, depth_s, trans_s, h, w, S, H, W, need_grad ? d_depth_s : nullptr,
+                               need_grad ? d_trans_s : nullptr);
   if (rc) return rc;
+  if (need_grad && (!d_depth_s || !d_trans_s)) return SFM_ERR_ARG;
+  // the kernels reach the gradient maps through pm; the stacked pointers are unused (non-null for the shared checks)
+  float* const any = need_grad ? d_depth_s[0] : nullptr;
   return loss_backward_common(tgt, src, nullptr, nullptr, &pm, params, ws, B, H, W, S, N, n_elem_global, gloss, need_grad,
-                              partials, pose, K, loss_out, d_depth, d_trans, d_pose, stream_);
+                              partials, n_extra, pose, K, loss_out, any, any, d_pose, stream_);
 }
 
 // ---- measurement aid (bench.py): per-launch HIP-event timing of the two calls above ----

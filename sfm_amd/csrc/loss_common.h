@@ -24,7 +24,12 @@ struct PyrMaps {
   const float* trans[kMaxScales];
   int h[kMaxScales], w[kMaxScales];
   float sy[kMaxScales], sx[kMaxScales];  // h / (float)H, w / (float)W (CalculateResizeScale)
+  // backward: where the gradients of the pyramid's maps are ADDED (the adjoint of the resize, evaluated in the kernel)
+  float* d_depth[kMaxScales];
+  float* d_trans[kMaxScales];
 };
+// LDS footprint of one backward tile (BTW x BTH full-size pixels) on a low-resolution level: every level is at most the
+// image's size, so the tile touches at most (BTH + 2) x (BTW + 2) of its cells (lo .. hi of the tile's corner pixels)
 
 // ---- streaming stencil geometry -------------------------------------------------------
 // One wave = one strip of 64 image columns (the outer two on each side are halo: 60 owned)

@@ -479,7 +479,8 @@ __global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, float
 // over the blocks, then a shuffle tree: a fixed order), thread 0 combines the <= 112 sums in fp64
 constexpr int kSmoothReduceThreads = 1024;
 __global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(SmoothArgs a, const float* __restrict__ blockp,
-                                                                             float* __restrict__ loss_out) {
+                                                                             float* __restrict__ loss_out,
+                                                                             double* __restrict__ loss_out_f64) {
   __shared__ double psum[kMaxMaps * kSmoothTerms];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int npair = a.n_maps * kSmoothTerms;
@@ -503,9 +504,40 @@ __global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(Smo
       const double coef[kSmoothTerms] = {0.25 * ws, 0.25 * ws, 0.75 * ws, 0.75 * ws, 0.75 * ws, 0.75 * ws, a.w_abs[m]};
       for (int j = 0; j < kSmoothTerms; ++j) total += coef[j] * psum[m * kSmoothTerms + j] / den[j];
     }
-    *loss_out = (float)total;
+    if (loss_out) *loss_out = (float)total;
+    if (loss_out_f64) *loss_out_f64 = (double)(float)total;  // the fp32 value, in the all-reduce buffer's type
   }
 }
+
+// ------------------------------------------------------------------ upstream-gradient scaling
+// The fused loss computes its gradients with the value (dL/dloss = 1); autograd hands the upstream scalar g over later,
+// as a device tensor.  sfm_scale_grads rescales every listed buffer in place from the scale it currently carries
+// (*cur, kept on the device) to *g and records the new scale - and does nothing at all when they are equal, which is
+// every plain loss.backward(): one launch that exits at once instead of a pass over all gradients.
+struct ScaleArgs {
+  float* p[2 * kMaxMaps + 2];
+  long n[2 * kMaxMaps + 2];
+  int blk0[2 * kMaxMaps + 3];
+  int count;
+};
+__global__ __launch_bounds__(kBlock) void scale_grads_kernel(ScaleArgs a, const float* __restrict__ g,
+                                                             const float* __restrict__ cur) {
+  const float to = *g, from = *cur;
+  if (to == from) return;
+  const float f = to / from;
+  int m = 0;
+  while (m + 1 < a.count && (int)blockIdx.x >= a.blk0[m + 1]) ++m;
+  const long k = ((long)blockIdx.x - a.blk0[m]) * kBlock * 4 + threadIdx.x * 4;
+  float* p = a.p[m];
+  if (k + 3 < a.n[m] && (((uintptr_t)p) & 15) == 0) {
+    float4 v = *reinterpret_cast<float4*>(p + k);
+    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+    *reinterpret_cast<float4*>(p + k) = v;
+  } else {
+    for (long j = k; j < a.n[m] && j < k + 4; ++j) p[j] *= f;
+  }
+}
+__global__ void scale_commit_kernel(const float* __restrict__ g, float* __restrict__ cur) { *cur = *g; }
 
 static inline int blocks_for(long n) { return (int)((n + kBlock - 1) / kBlock); }
 
@@ -594,6 +626,26 @@ extern "C" int sfm_pyramid_upsample_bwd(const float* gout, const int* h, const i
   for (int s = 0; s < S; ++s) a2.gin[s] = gin[s];
   a2.accumulate = accumulate != 0;
   SFM_DISPATCH_C(C, pyramid_upsample_bwd_y_kernel, dim3((unsigned)a2.blk0[S]), dim3(kBlock), 0, (hipStream_t)stream, a2, ws)
+  return sfm_last_error();
+}
+
+extern "C" int sfm_scale_grads(float* const* bufs, const long long* n, int count, const float* g, float* cur_scale,
+                               void* stream) {
+  if (!bufs || !n || !g || !cur_scale || count < 1 || count > 2 * kMaxMaps + 2) return SFM_ERR_ARG;
+  ScaleArgs a;
+  long blk = 0;
+  for (int m = 0; m < count; ++m) {
+    if (!bufs[m] || n[m] < 1) return SFM_ERR_ARG;
+    a.p[m] = bufs[m];
+    a.n[m] = (long)n[m];
+    a.blk0[m] = (int)blk;
+    blk += (n[m] + kBlock * 4 - 1) / (kBlock * 4);
+    if (blk > 2147483647L) return SFM_ERR_TOO_LARGE;
+  }
+  a.blk0[count] = (int)blk;
+  a.count = count;
+  hipLaunchKernelGGL(scale_grads_kernel, dim3((unsigned)blk), dim3(kBlock), 0, (hipStream_t)stream, a, g, cur_scale);
+  hipLaunchKernelGGL(scale_commit_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, cur_scale);
   return sfm_last_error();
 }
 
@@ -727,11 +779,11 @@ extern "C" long long sfm_smooth_workspace_floats(const int* h, const int* w, con
 
 extern "C" int sfm_smooth_loss(const float* const* maps, float* const* d_maps, const int* h, const int* w, const int* c,
                                const float* w_smooth, const float* w_abs, int n_maps, int B, int B_global, float gscale,
-                               float* ws, float* loss_out, void* stream) {
+                               float* ws, float* loss_out, double* loss_out_f64, void* stream) {
   SmoothArgs a;
   const int rc = fill_smooth(a, h, w, c, n_maps, B);
   if (rc) return rc;
-  if (!maps || !w_smooth || !w_abs || !ws || !loss_out || B_global < B) return SFM_ERR_ARG;
+  if (!maps || !w_smooth || !w_abs || !ws || (!loss_out && !loss_out_f64) || B_global < B) return SFM_ERR_ARG;
   for (int m = 0; m < n_maps; ++m) {
     if (!maps[m]) return SFM_ERR_ARG;
     a.map[m] = maps[m];
@@ -742,6 +794,7 @@ extern "C" int sfm_smooth_loss(const float* const* maps, float* const* d_maps, c
   a.b_global = (double)B_global;
   a.gscale = gscale;
   hipLaunchKernelGGL(smooth_loss_kernel, dim3((unsigned)a.blk0[n_maps]), dim3(kBlock), 0, (hipStream_t)stream, a, ws);
-  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(1), dim3(kSmoothReduceThreads), 0, (hipStream_t)stream, a, ws, loss_out);
+  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(1), dim3(kSmoothReduceThreads), 0, (hipStream_t)stream, a, ws, loss_out,
+                     loss_out_f64);
   return sfm_last_error();
 }

@@ -16,6 +16,7 @@ taken before its clip (utils.py:573-575).  Gradients are per-sample: no collecti
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Sequence
 
 import torch
@@ -86,25 +87,40 @@ class LossEngine:
         return partials
 
     def backward(self, tgt, src, K, depth, pose, trans, partials, n_elem_global: int, gloss: float = 1.0,
-                 need_grad: bool = True):
-        """Second half.  Returns (loss, d_depth [S,B,H,W], d_pose, d_trans [S,B,H,W,3N]); with pyramid LISTS for
-        ``depth`` / ``trans`` the two gradients are those of the resized maps (``pyramid_upsample_grad`` takes them
-        to the pyramid's sizes)."""
+                 need_grad: bool = True, d_trans_into: Optional[Sequence[Tensor]] = None, n_extra: int = 0):
+        """Second half.  Returns (loss, d_depth, d_pose, d_trans).  Stacked inputs: d_depth [S,B,H,W], d_trans
+        [S,B,H,W,3N].  Pyramid LISTS for ``depth`` / ``trans``: the adjoint of the resize runs in the kernel and the
+        gradients come back as lists at the pyramid's own sizes (``sfm_loss_backward_pyr``); ``d_trans_into``: maps
+        that already hold another term of the translation gradients (the regulariser's), added to in place;
+        ``n_extra``: fp64 values behind the sums in ``partials`` that are added to the loss (pyramid path only)."""
         B, H, W, S, N = self.dims
         loss = torch.empty((), dtype=torch.float32, device=self.device)
-        d_depth = torch.empty(S, B, H, W, dtype=torch.float32, device=self.device) if need_grad else None
-        d_trans = torch.empty(S, B, H, W, 3 * N, dtype=torch.float32, device=self.device) if need_grad else None
         d_pose = torch.empty_like(pose) if need_grad else None
         if isinstance(depth, (list, tuple)):
+            d_depth = d_trans = None
+            dd_tab = dt_tab = None
+            if need_grad:
+                # one zero-filled buffer for every level of d_depth (one fill launch), views per level
+                sizes = [t.shape[1] * t.shape[2] for t in trans]
+                flat = torch.zeros(B * sum(sizes), dtype=torch.float32, device=self.device)
+                d_depth, off = [], 0
+                for t, n in zip(trans, sizes):
+                    d_depth.append(flat[off:off + B * n].view(B, t.shape[1], t.shape[2], 1))
+                    off += B * n
+                d_trans = list(d_trans_into) if d_trans_into is not None else [torch.zeros_like(t) for t in trans]
+                if any(g.shape != t.shape or not g.is_contiguous() for g, t in zip(d_trans, trans)):
+                    raise ValueError("d_trans_into: one contiguous map per level, shaped like the level")
+                dd_tab, dt_tab = P._ptrs(d_depth), P._ptrs(d_trans)
             call("sfm_loss_backward_pyr", ptr(tgt), ptr(src), *self._pyr_args(depth, trans), ptr(self.params), ptr(self.ws),
-                 B, H, W, S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), ptr(pose), ptr(K), ptr(loss),
-                 ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
-        else:
-            call("sfm_loss_backward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
-                 S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), ptr(pose), ptr(K), ptr(loss),
-                 ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
+                 B, H, W, S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), int(n_extra), ptr(pose), ptr(K),
+                 ptr(loss), dd_tab, dt_tab, ptr(d_pose), stream_of(tgt))
+            return loss, d_depth, d_pose, d_trans
+        d_depth = torch.empty(S, B, H, W, dtype=torch.float32, device=self.device) if need_grad else None
+        d_trans = torch.empty(S, B, H, W, 3 * N, dtype=torch.float32, device=self.device) if need_grad else None
+        call("sfm_loss_backward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
+             S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), ptr(pose), ptr(K), ptr(loss),
+             ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
         return loss, d_depth, d_pose, d_trans
-
 
     # the three extra calls of the overlapped data-parallel step, one method each (the CPU test of the host sequence
     # replaces them by the oracle: tests/test_dp_gloo.py)
@@ -243,20 +259,35 @@ class _FusedTotalLoss(torch.autograd.Function):
             eng = engine if engine is not None else get_engine(B, H, W, S, N, tgt.device)
             if eng.dims != (B, H, W, S, N) or eng.device != tgt.device:
                 raise ValueError(f"engine was built for {eng.dims} on {eng.device}, got {(B, H, W, S, N)} on {tgt.device}")
-            if fuse_resize and S <= MAX_PYR_SCALES and not (overlap and _world_size(process_group) > 1):
+            fused_maps = fuse_resize and S <= MAX_PYR_SCALES and not (overlap and _world_size(process_group) > 1)
+            if fused_maps:
                 # the kernels read the pyramid at its native sizes and resize while loading (SfMLearner_uni.py:91, 113
-                # inside the warps): no [S,B,H,W,1+3N] intermediate
+                # inside the warps) and scatter the adjoint of the resize themselves: no [S,B,H,W,1+3N] intermediate
+                # in either direction
                 depth, trans = pred_depth, pred_exp
             else:
                 depth = P.pyramid_upsample(pred_depth, H, W).view(S, B, H, W)
                 trans = P.pyramid_upsample(pred_exp, H, W)
             n_elem = global_b * H * W * 3
             g_smooth, sm = None, None
+            buf = None
+            if fused_maps:
+                # ONE fp64 buffer = ONE all-reduce: the S*(3N+1) partial sums, then this rank's share of the regulariser,
+                # written there by its kernel and added to the loss by the backward kernel (no torch arithmetic at all)
+                buf = torch.empty(eng.n_partials + (1 if smooth_weight > 0 else 0), dtype=torch.float64, device=tgt.device)
             if smooth_weight > 0:
                 ws_, wa_ = P.smooth_weights(S, smooth_weight, explain_reg_weight)
-                sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need)
+                sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need,
+                                              out_f64=buf[eng.n_partials:] if buf is not None else None)
             try:
-                if overlap and _world_size(process_group) > 1:
+                if fused_maps:
+                    eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf)
+                    if global_b != B or process_group is not None:
+                        allreduce_partials(buf, process_group)
+                    d_into = g_smooth[S:] if g_smooth is not None else None
+                    total, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf, n_elem, 1.0, need,
+                                                                   d_trans_into=d_into, n_extra=buf.numel() - eng.n_partials)
+                elif overlap and _world_size(process_group) > 1:
                     # data parallel, collectives hidden: the splat-side sums and this rank's share of the regulariser
                     # travel in the first all-reduce (under the gather-side stencil), the min-reprojection sums in a
                     # second one (under the backward)
@@ -279,7 +310,13 @@ class _FusedTotalLoss(torch.autograd.Function):
                 eng.reinit()
                 _evict_engine(eng)
                 raise
-            if need:
+            if need and fused_maps:
+                g_disp = g_smooth[:S] if g_smooth is not None else []
+                # the scale the gradients carry (1 now); backward() moves them to the upstream scalar in place
+                ctx.cur_scale = torch.ones((), dtype=torch.float32, device=tgt.device)
+                ctx.in_place = True
+                ctx.save_for_backward(d_pose, *d_depth, *d_trans, *g_disp)
+            elif need:
                 g_depth = P.pyramid_upsample_grad(d_depth.view(S, B, H, W, 1), [(m.shape[1], m.shape[2]) for m in pred_depth])
                 # the regulariser's gradient of the translation maps is already in place: the adjoint adds to it
                 g_exp = P.pyramid_upsample_grad(d_trans, [(m.shape[1], m.shape[2]) for m in pred_exp],
@@ -290,7 +327,16 @@ class _FusedTotalLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None,) * 11 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
+        grads = list(ctx.saved_tensors)
+        if getattr(ctx, "in_place", False) and g.dtype == torch.float32 and g.numel() == 1 and g.device == grads[0].device:
+            # rescale in place from the scale they carry to the upstream scalar (sfm_scale_grads): a launch that exits
+            # at once for loss.backward() (g == 1), and safe when backward runs again with another g (retain_graph)
+            g = g.contiguous()
+            with torch.cuda.device(g.device):
+                n = (ctypes.c_longlong * len(grads))(*[t.numel() for t in grads])
+                call("sfm_scale_grads", P._ptrs(grads), n, len(grads), ptr(g), ptr(ctx.cur_scale), stream_of(g))
+            return (None,) * 11 + tuple(grads)
+        return (None,) * 11 + tuple(torch._foreach_mul(grads, g))
 
 
 def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor,

@@ -182,9 +182,10 @@ def normalize_disp(disp: Sequence[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
 
 # ----------------------------------------------------------------------------- smoothness
 def smooth_terms(maps: Sequence[Tensor], w_smooth: Sequence[float], w_abs: Sequence[float], global_batch: int,
-                 need_grad: bool, gscale: float = 1.0):
+                 need_grad: bool, gscale: float = 1.0, out_f64: Optional[Tensor] = None):
     """sum_m w_smooth[m] compute_smooth_loss(maps[m]) + w_abs[m] mean|maps[m]| -> (loss [] , grads or None).
-    Means divide by the global element count (``global_batch`` in place of the local batch size)."""
+    Means divide by the global element count (``global_batch`` in place of the local batch size).
+    ``out_f64``: a one-element fp64 tensor (a slot of the all-reduce buffer) that receives the value as well."""
     maps = [_check(m, f"maps[{k}]", 4) for k, m in enumerate(maps)]
     if not 1 <= len(maps) <= MAX_MAPS:
         raise ValueError(f"between 1 and {MAX_MAPS} maps")
@@ -202,7 +203,7 @@ def smooth_terms(maps: Sequence[Tensor], w_smooth: Sequence[float], w_abs: Seque
     with torch.cuda.device(dev):
         ws = torch.empty(lib.sfm_smooth_workspace_floats(h, w, c, len(maps), bsz), dtype=torch.float32, device=dev)
         call("sfm_smooth_loss", _ptrs(maps), _ptrs(grads) if grads else None, h, w, c, _floats(w_smooth), _floats(w_abs),
-             len(maps), bsz, int(global_batch), float(gscale), ptr(ws), ptr(loss), stream_of(loss))
+             len(maps), bsz, int(global_batch), float(gscale), ptr(ws), ptr(loss), ptr(out_f64), stream_of(loss))
     return loss, grads
 
 

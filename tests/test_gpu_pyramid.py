@@ -153,10 +153,12 @@ def test_total_loss_from_raw_network_outputs(dev):
     (1, 37, 53, 3, 2, [(37, 53), (19, 27), (10, 14)]),          # ragged: no ratio is a power of two
     (2, 24, 40, 3, 4, [(12, 20), (24, 40), (3, 5)]),            # seq = 5; a full-size level in the middle of the list
 ])
-def test_fused_resize_equals_materialised_resize_bit_for_bit(dev, B, H, W, S, N, sizes):
+def test_fused_resize_equals_materialised_resize(dev, B, H, W, S, N, sizes):
     """the warp kernels reading the pyramid at its native sizes (sfm_loss_forward_pyr /
-    sfm_loss_backward_pyr: resize_bilinear evaluated while loading) against the same step on maps resized first
-    (sfm_pyramid_upsample_fwd): one arithmetic, so the loss and every gradient must agree bit for bit."""
+    sfm_loss_backward_pyr: resize_bilinear evaluated while loading, its adjoint scattered by the backward kernel) against
+    the same step on maps resized first (sfm_pyramid_upsample_fwd / _bwd).  Forward: one arithmetic, so the loss and
+    d_pose (which never passes through the resize) agree bit for bit; the map gradients are summed in another order
+    (LDS footprints + float atomics instead of two gather passes): 1e-4 like every gradient."""
     import sfm_amd
     from sfm_amd import synth
     inp = synth.make_inputs(B, H, W, S=S, N=N, seed=71, pose_scale=0.03, full_res=False)
@@ -179,8 +181,9 @@ def test_fused_resize_equals_materialised_resize_bit_for_bit(dev, B, H, W, S, N,
     assert torch.equal(la, lb)
     assert torch.equal(pa, pb)
     for s in range(S):
-        assert torch.equal(da[s], db[s]), f"d_depth scale {s}"
-        assert torch.equal(ta[s], tb[s]), f"d_trans scale {s}"
+        assert da[s].shape == db[s].shape and ta[s].shape == tb[s].shape
+        assert rel_err(da[s], db[s]) <= 1e-5, f"d_depth scale {s}"     # same values, another summation order
+        assert rel_err(ta[s], tb[s]) <= 1e-5, f"d_trans scale {s}"
 
 
 def test_pyramid_entry_points_reject_bad_tables(dev):
