@@ -245,10 +245,9 @@ int sfm_smooth_loss(const float* const* maps, float* const* d_maps, const int* h
 
 /* Upstream-gradient scaling (no counterpart in the reference: TF's autodiff seeds d total_loss = 1).  The fused loss
  * computes its gradients together with the value; when the caller's autograd later supplies dL/d total_loss as a DEVICE
- * scalar *g, this rescales the count listed buffers (bufs / n: host arrays, count <= 34) in place from the scale they
- * currently carry, *cur_scale (a device float the caller initialises to 1), to *g, and stores *g there.  Equal scales
- * (every plain backward) make it a launch that exits at once. */
-int sfm_scale_grads(float* const* bufs, const long long* n, int count, const float* g, float* cur_scale, void* stream);
+ * scalar *g, this multiplies the count listed buffers (bufs / n: host arrays, count <= 34) by *g in place.  *g == 1
+ * (every plain backward) makes it a launch that exits at once instead of a pass over all gradients. */
+int sfm_scale_grads(float* const* bufs, const long long* n, int count, const float* g, void* stream);
 
 /* ---- ASPP dilated 3x3 convolutions: nets.py:451-471 (disp_bottleneck_dense) --------------------
  * slim.conv2d(x, Cout, [3, 3], rate=rate) of nets.py:457, 458, 463 - the convolution itself,

@@ -68,7 +68,7 @@ SIGNATURES = {
     "sfm_resize_bilinear_bwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_smooth_workspace_floats": [_P, _P, _P, _I, _I],
     "sfm_smooth_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
-    "sfm_scale_grads": [_P, _P, _I, _P, _P, _P],
+    "sfm_scale_grads": [_P, _P, _I, _P, _P],
     "sfm_aspp_conv3x3_bn_act_infer": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv1x1_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv1x1_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],

@@ -559,8 +559,11 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
   const float* __restrict__ tmap = PYR ? lv.t : trans + sb * C3 + 3 * i_base;
   const bool lowres = PYR && lv.lowres;  // workgroup-uniform
   int fx0 = 0, fy0 = 0, fw = 1, fh = 1;  // the tile's footprint on the level: cells [fy0, fy0 + fh) x [fx0, fx0 + fw)
+  int fgroup = 1;  // W = w * fgroup with fgroup a power of two (<= 64): aligned groups of fgroup lanes share their cells
   if constexpr (PYR) {
     if (lowres) {
+      const int q = d.W / lv.w;
+      if (q * lv.w == d.W && q >= 2 && (q & (q - 1)) == 0) fgroup = min(q, 64);
       fx0 = lerp_of(x0, lv.sx, lv.w).lo;
       fy0 = lerp_of(y0, lv.sy, lv.h).lo;
       fw = lerp_of(min(x0 + BTW, d.W) - 1, lv.sx, lv.w).hi - fx0 + 1;
@@ -608,11 +611,16 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
 #pragma unroll
     for (int i = 0; i < N; ++i) tr[i] = n_t[i];
     if (!lowres && it + 1 < kLossPPT) fetch1(it + 1);
-    if (u >= d.W || v >= d.H) continue;
+    const bool valid = u < d.W && v < d.H;
+    if (!PYR && !valid) continue;
     const int p = v * d.W + u;
     const float gxc = grid_coord(u, step_x, xmax), gyc = grid_coord(v, step_y, ymax);
     float ddsum = 0.0f;
     float dts[3 * N];
+#pragma unroll
+    for (int j = 0; j < 3 * N; ++j) dts[j] = 0.0f;
+    // (PYR: pixels beyond the image fall through with zero gradients - every lane takes part in the cross-lane sums below)
+    if (valid) {
 #pragma unroll
     for (int i0 = 0; i0 < N; i0 += SFM_BWD_PAIR) {
       constexpr int kPair = SFM_BWD_PAIR;
@@ -684,22 +692,47 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
         ddsum += dd_;
       }
     }
+    }  // valid
     if constexpr (PYR) {
       if (lowres) {
-        const Lerp ly = lerp_of(v, lv.sy, lv.h), lx = lerp_of(u, lv.sx, lv.w);
+        const Lerp ly = lerp_of(min(v, d.H - 1), lv.sy, lv.h), lx = lerp_of(min(u, d.W - 1), lv.sx, lv.w);
         const float xl = lx.l, yl = ly.l;  // plain locals: a select between struct members is a select between addresses
         const int cxl = lx.lo - fx0, cxh = lx.hi - fx0, cyl = (ly.lo - fy0) * fw, cyh = (ly.hi - fy0) * fw;
-        // one corner at a time (not unrolled): 7 products live, not 28
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-          const bool qx = (q & 1) != 0, qy = (q & 2) != 0;
-          const float wgt = (qx ? xl : 1.0f - xl) * (qy ? yl : 1.0f - yl);
-          double* f = foot + (size_t)((qy ? cyh : cyl) + (qx ? cxh : cxl)) * kFootV;
-          atomicAdd(f, (double)(wgt * ddsum));
+        if (fgroup > 1) {
+          // The lanes of a wave are 64 consecutive columns of one row.  With W = w * 2^k the 2^k lanes of an aligned
+          // group share their left cell (and their right one): summed across the group first (xor butterfly), one lane
+          // adds for all - the same cell hit by 2^k lanes of one ds_add is serialised 2^k-fold otherwise.
+          float a[kFootV], bq[kFootV];
+          a[0] = (1.0f - xl) * ddsum; bq[0] = xl * ddsum;
 #pragma unroll
-          for (int j = 0; j < 3 * N; ++j) atomicAdd(f + 1 + j, (double)(wgt * dts[j]));
+          for (int j = 0; j < 3 * N; ++j) { a[1 + j] = (1.0f - xl) * dts[j]; bq[1 + j] = xl * dts[j]; }
+          for (int m = 1; m < fgroup; m <<= 1) {
+#pragma unroll
+            for (int j = 0; j < kFootV; ++j) { a[j] += __shfl_xor(a[j], m, 64); bq[j] += __shfl_xor(bq[j], m, 64); }
+          }
+          if (((threadIdx.x & 63) & (fgroup - 1)) == 0) {
+#pragma unroll 1
+            for (int q = 0; q < 2; ++q) {  // the two cell rows of this pixel row
+              const float wy = q ? yl : 1.0f - yl;
+              double* f0 = foot + (size_t)((q ? cyh : cyl) + cxl) * kFootV;
+              double* f1 = foot + (size_t)((q ? cyh : cyl) + cxh) * kFootV;
+#pragma unroll
+              for (int j = 0; j < kFootV; ++j) { atomicAdd(f0 + j, (double)(wy * a[j])); atomicAdd(f1 + j, (double)(wy * bq[j])); }
+            }
+          }
+        } else {
+          // any other ratio: one corner at a time (not unrolled): 7 products live, not 28
+#pragma unroll 1
+          for (int q = 0; q < 4; ++q) {
+            const bool qx = (q & 1) != 0, qy = (q & 2) != 0;
+            const float wgt = (qx ? xl : 1.0f - xl) * (qy ? yl : 1.0f - yl);
+            double* f = foot + (size_t)((qy ? cyh : cyl) + (qx ? cxh : cxl)) * kFootV;
+            atomicAdd(f, (double)(wgt * ddsum));
+#pragma unroll
+            for (int j = 0; j < 3 * N; ++j) atomicAdd(f + 1 + j, (double)(wgt * dts[j]));
+          }
         }
-      } else {  // a level at full size: one writer per element, added to what the caller put there
+      } else if (valid) {  // a level at full size: one writer per element, added to what the caller put there
         float* dd = pm.d_depth[s] + (size_t)b * HW + p;
         *dd = *dd + ddsum;
         float* dt = pm.d_trans[s] + ((size_t)b * HW + p) * C3 + 3 * i_base;

@@ -36,7 +36,8 @@ struct NormArgs {
   int chunk0[kMaxMaps + 1];  // first chunk of each scale; a scale has B * chunks(s) chunks, item-major
   int S, B;
 };
-constexpr int kNormChunk = 4096;  // elements per workgroup (16 per thread)
+constexpr int kNormChunk = 1024;  // elements per workgroup (4 per thread): the maps are a few MB - more, smaller workgroups
+                                  // (4096: 190 workgroups for the whole c2 pyramid, fewer than CUs)
 
 struct NormItem {
   int s, b, chunk, nchunk, n;
@@ -407,78 +408,112 @@ constexpr int kSmoothTerms = 7;  // |dx|, |dy|, |dx2|, |dxdy|, |dydx|, |dy2|, |p
 
 __device__ __forceinline__ float sgnf(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
 
-constexpr int kSmoothPerThread = 8;
-constexpr int kSmoothPerBlock = kBlock * kSmoothPerThread;
+constexpr int kSmoothPixPerThread = 2;
+constexpr int kSmoothPerBlock = kBlock * kSmoothPixPerThread;  // PIXELS per workgroup
 
+// the 18 differences / 6 anchored terms of one element from its 13 samples (see the header of this section)
+struct SmoothK {
+  float k1x, k1y, k2xx, k2yy, k2xy, kab;
+};
+__device__ __forceinline__ float smooth_element(const SmoothK& c, float p00, float pm2, float pm1, float pp1, float pp2,
+                                                float qm2, float qm1, float qp1, float qp2, float dmm, float dmp, float dpm,
+                                                float dpp, int xi, int yi, int wi, int hi, float* __restrict__ t) {
+  // first differences, named by their anchor relative to (y, x): dx_ab = DX(y + a, x + b) = P(.., +1) - P(..)
+  const float dx_0m2 = pm1 - pm2, dx_0m1 = p00 - pm1, dx_00 = pp1 - p00, dx_0p1 = pp2 - pp1;
+  const float dx_p1m1 = qp1 - dpm, dx_p10 = dpp - qp1, dx_m1m1 = qm1 - dmm, dx_m10 = dmp - qm1;
+  const float dy_m20 = qm1 - qm2, dy_m10 = p00 - qm1, dy_00 = qp1 - p00, dy_p10 = qp2 - qp1;
+  const float dy_0m1 = dpm - pm1, dy_0p1 = dpp - pp1, dy_m1m1 = pm1 - dmm, dy_m1p1 = pp1 - dmp;
+  const bool xa = xi <= wi - 2, xb = xi >= 1, ya = yi <= hi - 2, yb = yi >= 1;
+  float g = c.kab * sgnf(p00);
+  t[6] += fabsf(p00);
+  if (xa) { t[0] += fabsf(dx_00); g -= c.k1x * sgnf(dx_00); }
+  if (xb) g += c.k1x * sgnf(dx_0m1);
+  if (ya) { t[1] += fabsf(dy_00); g -= c.k1y * sgnf(dy_00); }
+  if (yb) g += c.k1y * sgnf(dy_m10);
+  if (xi <= wi - 3) { const float v = dx_0p1 - dx_00; t[2] += fabsf(v); g += c.k2xx * sgnf(v); }   // dx2 anchored at x
+  if (xb && xa) g -= 2.0f * c.k2xx * sgnf(dx_00 - dx_0m1);                                          // ... at x-1
+  if (xi >= 2) g += c.k2xx * sgnf(dx_0m1 - dx_0m2);                                                 // ... at x-2
+  if (yi <= hi - 3) { const float v = dy_p10 - dy_00; t[5] += fabsf(v); g += c.k2yy * sgnf(v); }    // dy2
+  if (yb && ya) g -= 2.0f * c.k2yy * sgnf(dy_00 - dy_m10);
+  if (yi >= 2) g += c.k2yy * sgnf(dy_m10 - dy_m20);
+  if (ya && xa) {  // dxdy = DX(y+1, x) - DX(y, x), dydx = DY(y, x+1) - DY(y, x): equal in exact arithmetic only
+    const float v1 = dx_p10 - dx_00, v2 = dy_0p1 - dy_00;
+    t[3] += fabsf(v1); t[4] += fabsf(v2);
+    g += c.k2xy * (sgnf(v1) + sgnf(v2));
+  }
+  if (ya && xb) g -= c.k2xy * (sgnf(dx_p1m1 - dx_0m1) + sgnf(dy_00 - dy_0m1));    // anchored at (y, x-1)
+  if (yb && xa) g -= c.k2xy * (sgnf(dx_00 - dx_m10) + sgnf(dy_m1p1 - dy_m10));    // anchored at (y-1, x)
+  if (yb && xb) g += c.k2xy * (sgnf(dx_0m1 - dx_m1m1) + sgnf(dy_m10 - dy_m1m1));  // anchored at (y-1, x-1)
+  return g;
+}
+
+// One thread per PIXEL (the index arithmetic - two divisions and eight clamped offsets - once per pixel, not per
+// element), the channels in groups of 3 (12-byte loads of the 13 neighbours) or singly.
 __global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, float* __restrict__ blockp) {
   __shared__ float red[4 * kSmoothTerms];
   int m = 0;
   while (m + 1 < a.n_maps && (int)blockIdx.x >= a.blk0[m + 1]) ++m;
   const unsigned h = a.h[m], w = a.w[m], C = a.c[m];
-  const unsigned total = (unsigned)a.B * h * w * C;  // < 2^31 (checked on the host)
+  const unsigned npix = (unsigned)a.B * h * w;  // < 2^31 (checked on the host)
   const double bg = a.b_global;
   const float ws = a.w_smooth[m];
-  const float k1x = (float)(0.25 * ws / (bg * h * (w - 1) * C)), k1y = (float)(0.25 * ws / (bg * (h - 1) * w * C));
-  const float k2xx = (float)(0.75 * ws / (bg * h * (w - 2) * C)), k2yy = (float)(0.75 * ws / (bg * (h - 2) * w * C));
-  const float k2xy = (float)(0.75 * ws / (bg * (h - 1) * (w - 1) * C));
-  const float kab = (float)(a.w_abs[m] / (bg * h * w * C));
+  SmoothK c;
+  c.k1x = (float)(0.25 * ws / (bg * h * (w - 1) * C)); c.k1y = (float)(0.25 * ws / (bg * (h - 1) * w * C));
+  c.k2xx = (float)(0.75 * ws / (bg * h * (w - 2) * C)); c.k2yy = (float)(0.75 * ws / (bg * (h - 2) * w * C));
+  c.k2xy = (float)(0.75 * ws / (bg * (h - 1) * (w - 1) * C));
+  c.kab = (float)(a.w_abs[m] / (bg * h * w * C));
   const float* __restrict__ map = a.map[m];
   float* __restrict__ grad = a.grad[m];
+  const float gs = a.gscale;
   float t[kSmoothTerms];
 #pragma unroll
   for (int j = 0; j < kSmoothTerms; ++j) t[j] = 0.f;
-#pragma unroll 2
-  for (int it = 0; it < kSmoothPerThread; ++it) {
-    const unsigned k = (blockIdx.x - a.blk0[m]) * kSmoothPerBlock + it * kBlock + threadIdx.x;
-    if (k >= total) break;
-    const unsigned pix = k / C, row = pix / w, x = pix - row * w, y = row % h;
+  for (int it = 0; it < kSmoothPixPerThread; ++it) {
+    const unsigned pix = (blockIdx.x - a.blk0[m]) * kSmoothPerBlock + it * kBlock + threadIdx.x;
+    if (pix >= npix) break;
+    const unsigned row = pix / w, x = pix - row * w, y = row % h;
     const int xi = (int)x, yi = (int)y, wi = (int)w, hi = (int)h;
-    // the 13 samples every difference below is made of: row y at x-2..x+2, column x at y-2..y+2 and the
-    // four diagonal neighbours; clamped addresses (a clamped sample is never used: see the range tests)
-    const float* __restrict__ p = map + k;  // this element; neighbours by (clamped) signed offsets
+    // the 13 samples every difference is made of: row y at x-2..x+2, column x at y-2..y+2 and the four diagonal
+    // neighbours; clamped addresses (a clamped sample is never used: see the range tests)
     const int sx = (int)C, sy = (int)(w * C);
     const int oxm2 = (max(xi - 2, 0) - xi) * sx, oxm1 = (max(xi - 1, 0) - xi) * sx;
     const int oxp1 = (min(xi + 1, wi - 1) - xi) * sx, oxp2 = (min(xi + 2, wi - 1) - xi) * sx;
     const int oym2 = (max(yi - 2, 0) - yi) * sy, oym1 = (max(yi - 1, 0) - yi) * sy;
     const int oyp1 = (min(yi + 1, hi - 1) - yi) * sy, oyp2 = (min(yi + 2, hi - 1) - yi) * sy;
-    const float p00 = p[0], pm2 = p[oxm2], pm1 = p[oxm1], pp1 = p[oxp1], pp2 = p[oxp2];
-    const float qm2 = p[oym2], qm1 = p[oym1], qp1 = p[oyp1], qp2 = p[oyp2];
-    const float dmm = p[oym1 + oxm1], dmp = p[oym1 + oxp1], dpm = p[oyp1 + oxm1], dpp = p[oyp1 + oxp1];
-    // first differences, named by their anchor relative to (y, x): dx_ab = DX(y + a, x + b) = P(.., +1) - P(..)
-    const float dx_0m2 = pm1 - pm2, dx_0m1 = p00 - pm1, dx_00 = pp1 - p00, dx_0p1 = pp2 - pp1;
-    const float dx_p1m1 = qp1 - dpm, dx_p10 = dpp - qp1, dx_m1m1 = qm1 - dmm, dx_m10 = dmp - qm1;
-    const float dy_m20 = qm1 - qm2, dy_m10 = p00 - qm1, dy_00 = qp1 - p00, dy_p10 = qp2 - qp1;
-    const float dy_0m1 = dpm - pm1, dy_0p1 = dpp - pp1, dy_m1m1 = pm1 - dmm, dy_m1p1 = pp1 - dmp;
-    const bool xa = xi <= wi - 2, xb = xi >= 1, ya = yi <= hi - 2, yb = yi >= 1;
-    float g = kab * sgnf(p00);
-    t[6] += fabsf(p00);
-    if (xa) { t[0] += fabsf(dx_00); g -= k1x * sgnf(dx_00); }
-    if (xb) g += k1x * sgnf(dx_0m1);
-    if (ya) { t[1] += fabsf(dy_00); g -= k1y * sgnf(dy_00); }
-    if (yb) g += k1y * sgnf(dy_m10);
-    if (xi <= wi - 3) { const float v = dx_0p1 - dx_00; t[2] += fabsf(v); g += k2xx * sgnf(v); }   // dx2 anchored at x
-    if (xb && xa) g -= 2.0f * k2xx * sgnf(dx_00 - dx_0m1);                                          // ... at x-1
-    if (xi >= 2) g += k2xx * sgnf(dx_0m1 - dx_0m2);                                                 // ... at x-2
-    if (yi <= hi - 3) { const float v = dy_p10 - dy_00; t[5] += fabsf(v); g += k2yy * sgnf(v); }    // dy2
-    if (yb && ya) g -= 2.0f * k2yy * sgnf(dy_00 - dy_m10);
-    if (yi >= 2) g += k2yy * sgnf(dy_m10 - dy_m20);
-    if (ya && xa) {  // dxdy = DX(y+1, x) - DX(y, x), dydx = DY(y, x+1) - DY(y, x): equal in exact arithmetic only
-      const float v1 = dx_p10 - dx_00, v2 = dy_0p1 - dy_00;
-      t[3] += fabsf(v1); t[4] += fabsf(v2);
-      g += k2xy * (sgnf(v1) + sgnf(v2));
+    const float* __restrict__ p = map + (size_t)pix * C;
+    float* __restrict__ go = grad ? grad + (size_t)pix * C : nullptr;
+    if (C % 3 == 0) {
+      for (unsigned ch = 0; ch < C; ch += 3) {
+        const float* q = p + ch;
+        const f3 p00 = ld3(q), pm2 = ld3(q + oxm2), pm1 = ld3(q + oxm1), pp1 = ld3(q + oxp1), pp2 = ld3(q + oxp2);
+        const f3 qm2 = ld3(q + oym2), qm1 = ld3(q + oym1), qp1 = ld3(q + oyp1), qp2 = ld3(q + oyp2);
+        const f3 dmm = ld3(q + oym1 + oxm1), dmp = ld3(q + oym1 + oxp1), dpm = ld3(q + oyp1 + oxm1), dpp = ld3(q + oyp1 + oxp1);
+        const float g0 = smooth_element(c, p00.x, pm2.x, pm1.x, pp1.x, pp2.x, qm2.x, qm1.x, qp1.x, qp2.x, dmm.x, dmp.x, dpm.x, dpp.x, xi, yi, wi, hi, t);
+        const float g1 = smooth_element(c, p00.y, pm2.y, pm1.y, pp1.y, pp2.y, qm2.y, qm1.y, qp1.y, qp2.y, dmm.y, dmp.y, dpm.y, dpp.y, xi, yi, wi, hi, t);
+        const float g2 = smooth_element(c, p00.z, pm2.z, pm1.z, pp1.z, pp2.z, qm2.z, qm1.z, qp1.z, qp2.z, dmm.z, dmp.z, dpm.z, dpp.z, xi, yi, wi, hi, t);
+        if (go) st3(go + ch, gs * g0, gs * g1, gs * g2);
+      }
+    } else {
+      for (unsigned ch = 0; ch < C; ++ch) {
+        const float* q = p + ch;
+        const float g0 = smooth_element(c, q[0], q[oxm2], q[oxm1], q[oxp1], q[oxp2], q[oym2], q[oym1], q[oyp1], q[oyp2],
+                                        q[oym1 + oxm1], q[oym1 + oxp1], q[oyp1 + oxm1], q[oyp1 + oxp1], xi, yi, wi, hi, t);
+        if (go) go[ch] = gs * g0;
+      }
     }
-    if (ya && xb) g -= k2xy * (sgnf(dx_p1m1 - dx_0m1) + sgnf(dy_00 - dy_0m1));    // anchored at (y, x-1)
-    if (yb && xa) g -= k2xy * (sgnf(dx_00 - dx_m10) + sgnf(dy_m1p1 - dy_m10));    // anchored at (y-1, x)
-    if (yb && xb) g += k2xy * (sgnf(dx_0m1 - dx_m1m1) + sgnf(dy_m10 - dy_m1m1));  // anchored at (y-1, x-1)
-    if (grad) grad[k] = a.gscale * g;
   }
   block_sum_store<kSmoothTerms>(t, red, blockp + (size_t)blockIdx.x * kSmoothTerms);
 }
 
 // one workgroup of 16 waves: wave v sums the block partials of the (map, term) pairs v, v+16, ... (lanes stride
-// over the blocks, then a shuffle tree: a fixed order), thread 0 combines the <= 112 sums in fp64
+// over the blocks, then a shuffle tree: a fixed order) and weights the sum with coef / denominator (formed on the host
+// in fp64); wave 0 adds the <= 112 weighted terms, again in a fixed order
 constexpr int kSmoothReduceThreads = 1024;
-__global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(SmoothArgs a, const float* __restrict__ blockp,
+struct SmoothCoef {
+  double k[kMaxMaps * kSmoothTerms];
+};
+__global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(SmoothArgs a, SmoothCoef kc,
+                                                                             const float* __restrict__ blockp,
                                                                              float* __restrict__ loss_out,
                                                                              double* __restrict__ loss_out_f64) {
   __shared__ double psum[kMaxMaps * kSmoothTerms];
@@ -486,45 +521,44 @@ __global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(Smo
   const int npair = a.n_maps * kSmoothTerms;
   for (int pr = wave; pr < npair; pr += kSmoothReduceThreads / 64) {
     const int m = pr / kSmoothTerms, j = pr - m * kSmoothTerms;
-    double acc = 0.0;
-    for (int k = a.blk0[m] + lane; k < a.blk0[m + 1]; k += 64) acc += (double)blockp[(size_t)k * kSmoothTerms + j];
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = a.blk0[m] + lane;
+    for (; k + 64 < a.blk0[m + 1]; k += 128) {  // two loads in flight per lane
+      acc0 += (double)blockp[(size_t)k * kSmoothTerms + j];
+      acc1 += (double)blockp[(size_t)(k + 64) * kSmoothTerms + j];
+    }
+    if (k < a.blk0[m + 1]) acc0 += (double)blockp[(size_t)k * kSmoothTerms + j];
+    double acc = acc0 + acc1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) psum[pr] = acc;
+    if (lane == 0) psum[pr] = acc * kc.k[pr];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
     double total = 0.0;
-    for (int m = 0; m < a.n_maps; ++m) {
-      const double h = a.h[m], w = a.w[m], C = a.c[m], bg = a.b_global;
-      const double den[kSmoothTerms] = {bg * h * (w - 1) * C, bg * (h - 1) * w * C, bg * h * (w - 2) * C,
-                                        bg * (h - 1) * (w - 1) * C, bg * (h - 1) * (w - 1) * C, bg * (h - 2) * w * C,
-                                        bg * h * w * C};
-      const double ws = a.w_smooth[m];
-      const double coef[kSmoothTerms] = {0.25 * ws, 0.25 * ws, 0.75 * ws, 0.75 * ws, 0.75 * ws, 0.75 * ws, a.w_abs[m]};
-      for (int j = 0; j < kSmoothTerms; ++j) total += coef[j] * psum[m * kSmoothTerms + j] / den[j];
+    for (int k = lane; k < npair; k += 64) total += psum[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if (lane == 0) {
+      if (loss_out) *loss_out = (float)total;
+      if (loss_out_f64) *loss_out_f64 = (double)(float)total;  // the fp32 value, in the all-reduce buffer's type
     }
-    if (loss_out) *loss_out = (float)total;
-    if (loss_out_f64) *loss_out_f64 = (double)(float)total;  // the fp32 value, in the all-reduce buffer's type
   }
 }
 
 // ------------------------------------------------------------------ upstream-gradient scaling
 // The fused loss computes its gradients with the value (dL/dloss = 1); autograd hands the upstream scalar g over later,
-// as a device tensor.  sfm_scale_grads rescales every listed buffer in place from the scale it currently carries
-// (*cur, kept on the device) to *g and records the new scale - and does nothing at all when they are equal, which is
-// every plain loss.backward(): one launch that exits at once instead of a pass over all gradients.
+// as a device tensor.  sfm_scale_grads multiplies every listed buffer by *g in place - and does nothing at all when
+// *g == 1, which is every plain loss.backward(): one launch that exits at once instead of a pass over all gradients.
 struct ScaleArgs {
   float* p[2 * kMaxMaps + 2];
   long n[2 * kMaxMaps + 2];
   int blk0[2 * kMaxMaps + 3];
   int count;
 };
-__global__ __launch_bounds__(kBlock) void scale_grads_kernel(ScaleArgs a, const float* __restrict__ g,
-                                                             const float* __restrict__ cur) {
-  const float to = *g, from = *cur;
-  if (to == from) return;
-  const float f = to / from;
+__global__ __launch_bounds__(kBlock) void scale_grads_kernel(ScaleArgs a, const float* __restrict__ g) {
+  const float f = *g;
+  if (f == 1.0f) return;
   int m = 0;
   while (m + 1 < a.count && (int)blockIdx.x >= a.blk0[m + 1]) ++m;
   const long k = ((long)blockIdx.x - a.blk0[m]) * kBlock * 4 + threadIdx.x * 4;
@@ -537,7 +571,6 @@ __global__ __launch_bounds__(kBlock) void scale_grads_kernel(ScaleArgs a, const 
     for (long j = k; j < a.n[m] && j < k + 4; ++j) p[j] *= f;
   }
 }
-__global__ void scale_commit_kernel(const float* __restrict__ g, float* __restrict__ cur) { *cur = *g; }
 
 static inline int blocks_for(long n) { return (int)((n + kBlock - 1) / kBlock); }
 
@@ -629,9 +662,8 @@ extern "C" int sfm_pyramid_upsample_bwd(const float* gout, const int* h, const i
   return sfm_last_error();
 }
 
-extern "C" int sfm_scale_grads(float* const* bufs, const long long* n, int count, const float* g, float* cur_scale,
-                               void* stream) {
-  if (!bufs || !n || !g || !cur_scale || count < 1 || count > 2 * kMaxMaps + 2) return SFM_ERR_ARG;
+extern "C" int sfm_scale_grads(float* const* bufs, const long long* n, int count, const float* g, void* stream) {
+  if (!bufs || !n || !g || count < 1 || count > 2 * kMaxMaps + 2) return SFM_ERR_ARG;
   ScaleArgs a;
   long blk = 0;
   for (int m = 0; m < count; ++m) {
@@ -644,8 +676,7 @@ extern "C" int sfm_scale_grads(float* const* bufs, const long long* n, int count
   }
   a.blk0[count] = (int)blk;
   a.count = count;
-  hipLaunchKernelGGL(scale_grads_kernel, dim3((unsigned)blk), dim3(kBlock), 0, (hipStream_t)stream, a, g, cur_scale);
-  hipLaunchKernelGGL(scale_commit_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, cur_scale);
+  hipLaunchKernelGGL(scale_grads_kernel, dim3((unsigned)blk), dim3(kBlock), 0, (hipStream_t)stream, a, g);
   return sfm_last_error();
 }
 
@@ -762,7 +793,8 @@ static int fill_smooth(SmoothArgs& a, const int* h, const int* w, const int* c, 
     a.blk0[m] = (int)blk;
     const long nel = (long)B * h[m] * w[m] * c[m];
     if (nel > 2147483647L) return SFM_ERR_TOO_LARGE;
-    blk += (nel + kSmoothPerBlock - 1) / kSmoothPerBlock;
+    const long npix = (long)B * h[m] * w[m];
+    blk += (npix + kSmoothPerBlock - 1) / kSmoothPerBlock;
   }
   a.blk0[n_maps] = (int)blk;
   a.n_maps = n_maps;
@@ -794,7 +826,16 @@ extern "C" int sfm_smooth_loss(const float* const* maps, float* const* d_maps, c
   a.b_global = (double)B_global;
   a.gscale = gscale;
   hipLaunchKernelGGL(smooth_loss_kernel, dim3((unsigned)a.blk0[n_maps]), dim3(kBlock), 0, (hipStream_t)stream, a, ws);
-  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(1), dim3(kSmoothReduceThreads), 0, (hipStream_t)stream, a, ws, loss_out,
+  SmoothCoef kc;
+  for (int m = 0; m < n_maps; ++m) {
+    const double hh = h[m], ww = w[m], C = c[m], bg = a.b_global, wsm = w_smooth[m];
+    const double den[kSmoothTerms] = {bg * hh * (ww - 1) * C, bg * (hh - 1) * ww * C, bg * hh * (ww - 2) * C,
+                                      bg * (hh - 1) * (ww - 1) * C, bg * (hh - 1) * (ww - 1) * C, bg * (hh - 2) * ww * C,
+                                      bg * hh * ww * C};
+    const double coef[kSmoothTerms] = {0.25 * wsm, 0.25 * wsm, 0.75 * wsm, 0.75 * wsm, 0.75 * wsm, 0.75 * wsm, (double)w_abs[m]};
+    for (int j = 0; j < kSmoothTerms; ++j) kc.k[m * kSmoothTerms + j] = coef[j] / den[j];
+  }
+  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(1), dim3(kSmoothReduceThreads), 0, (hipStream_t)stream, a, kc, ws, loss_out,
                      loss_out_f64);
   return sfm_last_error();
 }

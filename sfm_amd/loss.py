@@ -312,10 +312,10 @@ class _FusedTotalLoss(torch.autograd.Function):
                 raise
             if need and fused_maps:
                 g_disp = g_smooth[:S] if g_smooth is not None else []
-                # the scale the gradients carry (1 now); backward() moves them to the upstream scalar in place
-                ctx.cur_scale = torch.ones((), dtype=torch.float32, device=tgt.device)
-                ctx.in_place = True
-                ctx.save_for_backward(d_pose, *d_depth, *d_trans, *g_disp)
+                # (held as a plain attribute and handed over by backward(): tensors returned from save_for_backward
+                # are still referenced by the graph, so autograd would CLONE each into .grad - a second pass over
+                # every gradient; handed over with no other owner they become the leaves' .grad as they are)
+                ctx.owned_grads = [d_pose, *d_depth, *d_trans, *g_disp]
             elif need:
                 g_depth = P.pyramid_upsample_grad(d_depth.view(S, B, H, W, 1), [(m.shape[1], m.shape[2]) for m in pred_depth])
                 # the regulariser's gradient of the translation maps is already in place: the adjoint adds to it
@@ -327,16 +327,20 @@ class _FusedTotalLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        grads = list(ctx.saved_tensors)
-        if getattr(ctx, "in_place", False) and g.dtype == torch.float32 and g.numel() == 1 and g.device == grads[0].device:
-            # rescale in place from the scale they carry to the upstream scalar (sfm_scale_grads): a launch that exits
-            # at once for loss.backward() (g == 1), and safe when backward runs again with another g (retain_graph)
-            g = g.contiguous()
+        if hasattr(ctx, "owned_grads"):
+            grads = ctx.owned_grads
+            if grads is None:
+                raise RuntimeError("multi_scale_loss(fused=True, fuse_resize=True) hands its gradients over once: a second "
+                                   "backward through the same graph needs fuse_resize=False")
+            ctx.owned_grads = None
+            # multiply in place by the upstream scalar (sfm_scale_grads): a launch that exits at once for loss.backward()
+            # (g == 1) instead of a pass over every gradient
+            g = g.to(dtype=torch.float32, device=grads[0].device).reshape(()).contiguous()
             with torch.cuda.device(g.device):
                 n = (ctypes.c_longlong * len(grads))(*[t.numel() for t in grads])
-                call("sfm_scale_grads", P._ptrs(grads), n, len(grads), ptr(g), ptr(ctx.cur_scale), stream_of(g))
+                call("sfm_scale_grads", P._ptrs(grads), n, len(grads), ptr(g), stream_of(g))
             return (None,) * 11 + tuple(grads)
-        return (None,) * 11 + tuple(torch._foreach_mul(grads, g))
+        return (None,) * 11 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 
 def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor,

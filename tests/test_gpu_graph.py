@@ -1,5 +1,7 @@
-"""The captured-graph form of total_loss (sfm_amd.GraphedTotalLoss) must give bit-identical loss and gradients to the
-eager call sequence it captured, call after call with fresh inputs."""
+"""The captured-graph form of total_loss (sfm_amd.GraphedTotalLoss) must give the loss and the pose gradient of the eager
+call sequence it captured bit for bit, call after call with fresh inputs; the map gradients pass through the float
+atomics of the fused resize adjoint (cells on tile borders have up to four adders), so they agree to the last bits
+only: 1e-6 of the tensor's maximum."""
 import pytest
 import torch
 
@@ -24,5 +26,6 @@ def test_graphed_total_loss_matches_eager(dev):
         grads = torch.autograd.grad(loss, raw + trans + [pose])
         gl, g_raw, g_pose, g_trans = g([r.detach() for r in raw], pose.detach(), [t.detach() for t in trans])
         assert torch.equal(gl, loss.detach())
-        for a, b in zip(g_raw + g_trans + [g_pose], grads):
-            assert torch.equal(a, b)
+        assert torch.equal(g_pose, grads[-1])
+        for a, b in zip(g_raw + g_trans, grads[:-1]):
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
