@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBlock) SFM_WPE_SPLAT void loss_stencil_splat_kerne
 
 // Both kernels go to the caller's stream, back to back.  Running them side by side (the gather side on a second stream,
 // forked and joined with events) was measured at c2 and is SLOWER: 116 us for the pair instead of 96 (gather 93 us
-// instead of 43, splat 80 instead of 56; profiles/r02_fork_experiment.txt) - together they want more VALU issue slots
+// instead of 43, splat 80 instead of 56; profiles/r02_c2_experiments.txt) - together they want more VALU issue slots
 // and cache than the chip has, so they only get in each other's way.
 int launch_loss_stencil(const StencilArgs& a, bool need_grad, int which, hipStream_t stream) {
   constexpr int WPB = kBlock / 64;
