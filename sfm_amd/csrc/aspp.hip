@@ -21,6 +21,8 @@
 // bitwise reproducible, no atomics.
 #include "sfm_device.h"
 #include "sfm_internal.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace sfm {
 
@@ -65,8 +67,9 @@ __device__ __forceinline__ float ep_apply(float v, float sc, float sh, int act) 
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 template <int TM, int TN>
 __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], float* __restrict__ out, long ld, long row0,
-                                          long rows, int col0, const Epilogue ep = Epilogue{nullptr, nullptr, 0}) {
-  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+                                          long rows, int col0, const Epilogue ep = Epilogue{nullptr, nullptr, 0},
+                                          int lane = threadIdx.x & 63) {
+  const int c = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -82,99 +85,304 @@ __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], float* __
 }
 
 // ------------------------------------------------------------------ forward / backward data
-// grid (ceil(M / BM), Cout / BN, splits); a split covers taps [z * tps, (z + 1) * tps) and writes
-// its own slab out + z * split_stride.
-template <int BM, int BN, int WM, int WN, bool EP>  // EP: apply the epilogue (its own instantiation: the plain kernel stays as it was)
-// waves_per_eu(2, 3): without the upper bound hipcc caps the 128x128 configuration at 128 VGPRs (4 waves per
-// SIMD) and spills the prefetch registers to scratch inside the K loop
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(2, 3))) void aspp_conv_kernel(
-    const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out, int B, int H, int W, int Cin,
-    int Cout, int rate, int tps, long split_stride, Epilogue ep) {
-  constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr int LDA = BM + 1, LDB = BN + 4;
-  constexpr int A_IT = BM * BK / 4 / NT, B_IT = BK * BN / 4 / NT;
+// Staging: global_load_lds_dwordx4 (LDS-DMA, gfx950) writes 16 bytes per lane straight into LDS, two tile buffers
+// alternate, and a K-step has ONE barrier - the DMA of step s + 1 is issued before the MFMAs of step s and lands under
+// them (no global -> VGPR -> ds_write phase between the MFMA phases, no prefetch registers).  What the DMA dictates: a
+// wave instruction fills 64 consecutive 16-byte slots, so the LDS image is decided by WHICH element each lane fetches,
+// not by where it stores it.
+//   A tile [BM rows][8 slots of 4 channels]: slot(m, g) = m * 8 + (g ^ ((m >> 1) & 7)).  An MFMA operand read is one
+//     ds_read_b128 per lane - lane (r, h) takes the four channels of group 2 c + h of row r - and the xor spreads the 16
+//     lanes of every b128 service group over all 16 slot columns: conflict-free.  The four values feed four MFMAs, whose
+//     k index is therefore 8 c + 4 h + j: lanes 0-31 and 32-63 of one MFMA carry k and k + 4 (any pairing of the K
+//     elements is a valid GEMM as long as the B operand pairs them the same way).
+//   B tile [BK][BN] row-major, as the weights lie in memory: lane (r, h) reads B[8 c + 4 h + j][n0 + r] (ds_read_b32,
+//     consecutive lanes on consecutive words).
+// Rows beyond the image / the padding ring fetch a 16-byte block of zeros instead.
+//
+// Work split: stream-K.  All 11 convolutions of the decoder have the same FLOPs but 52 ... 1664 output tiles; the
+// tiles x K-steps units of a problem are dealt in ONE contiguous range per workgroup to 2 workgroups per CU (what the
+// 64-80 KB of LDS admit), so every CU runs two workgroups from start to end and all finish together - with whole-tile
+// work items the last round ran half empty and cost 120 -> 176 us.  A workgroup whose range ends inside a tile
+// writes the partial tile to a slab of its own (at most two per workgroup: head and tail); aspp_sk_fixup_kernel adds
+// the slabs of a tile in workgroup order (fixed order: bitwise reproducible, no atomics) and applies the epilogue.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+#ifdef SFM_TRACE
+__device__ long long g_trace[32768];
+extern "C" int sfm_debug_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(long long) * 32768); }
+#endif
+
+// First unit of (logical) workgroup w: equal ranges.  (Of the two workgroups of a CU the one dispatched first finishes
+// the same range ~8 % sooner; handing it 25/24 or 26/24 of the mean made every layer slower, profiles/r02_aspp_kloop.txt.)
+__host__ __device__ inline long sk_first_unit(long w, long total, long nwg) { return w * total / nwg; }
+
+template <int BM, int BN, int WM, int WN, bool EP>
+__global__ __launch_bounds__(conv_threads(BM, BN, WM, WN)) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out,
+                         float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps, Epilogue ep) {
+  constexpr int NW = (BM / WM) * (BN / WN), NL = NW;  // multiplier waves, loader waves
   constexpr int TM = WM / 32, TN = WN / 32;
-  static_assert(A_IT >= 1 && B_IT >= 1 && (BM * BK / 4) % NT == 0 && (BK * BN / 4) % NT == 0, "tile / thread mismatch");
-  __shared__ float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-  const int tid = threadIdx.x, wave = tid >> 6;
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN;
+  constexpr int A_IT = A_FLOATS / 256 / NL, B_IT = B_FLOATS / 256 / NL;  // DMA instructions per loader wave and K-step
+  static_assert(A_IT >= 1 && B_IT >= 1 && A_FLOATS % (256 * NL) == 0 && B_FLOATS % (256 * NL) == 0, "tile / wave mismatch");
+  // two tile buffers as two DISTINCT arrays: the compiler orders an LDS read behind every LDS-DMA it cannot prove
+  // disjoint (s_waitcnt vmcnt(0) in front of the first ds_read), and only distinct __shared__ objects carry that proof
+  __shared__ __attribute__((aligned(1024))) float lds0[A_FLOATS + B_FLOATS];
+  __shared__ __attribute__((aligned(1024))) float lds1[A_FLOATS + B_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave_all >= NW;
+  const int wave = loader ? wave_all - NW : wave_all;  // index within the role
   const int wm0 = (wave % (BM / WM)) * WM, wn0 = (wave / (BM / WM)) * WN;
   const long M = (long)B * H * W;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int tap0 = blockIdx.z * tps, tap1 = min(9, tap0 + tps);
+  const int csteps = Cin / BK, K = ntaps * csteps, ntn = Cout / BN;
+  const long total = ((M + BM - 1) / BM) * ntn * K;
+  // workgroups are dealt to the 8 XCDs round-robin: each XCD (= each L2) takes one contiguous eighth of the unit range
+  const long wg = gridDim.x % 8 == 0 ? (long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (long)blockIdx.x;
+  const long u0 = sk_first_unit(wg, total, gridDim.x), u1 = sk_first_unit(wg + 1, total, gridDim.x);
 
-  // the A rows this thread stages: row = it * (NT / 8) + tid / 8, channels kc .. kc + 3 of the K-step
-  const int kc = (tid & 7) * 4;
-  int py[A_IT], px[A_IT];
-  long pb[A_IT];
+  // B: instruction q of this wave fills floats (wave * B_IT + q) * 256 .. + 256 of the [BK][BN] tile
+  int boff[B_IT];
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    const long m = m0 + it * (NT / 8) + (tid >> 3);
-    if (m < M) {
-      const long bi = m / ((long)H * W);
-      const int rem = (int)(m - bi * H * W);
-      py[it] = rem / W;
-      px[it] = rem - py[it] * W;
-      pb[it] = bi * H * W;
-    } else {
-      py[it] = px[it] = 0;
-      pb[it] = -1;
-    }
+  for (int q = 0; q < B_IT; ++q) {
+    const int f = (wave * B_IT + q) * 256 + lane * 4;
+    boff[q] = ((f / BN) * Cout + f % BN) * 4;
   }
-  float4 ra[A_IT], rb[B_IT];
-  auto load_tiles = [&](int tap, int c0) {
-    const int dy = (tap / 3 - 1) * rate, dx = (tap % 3 - 1) * rate;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int y = py[it] + dy, x = px[it] + dx;
-      ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pb[it] >= 0 && y >= 0 && y < H && x >= 0 && x < W)
-        ra[it] = *reinterpret_cast<const float4*>(in + (pb[it] + (long)y * W + x) * Cin + c0 + kc);
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int idx = it * NT + tid, k = idx / (BN / 4), n4 = idx % (BN / 4);
-      rb[it] = *reinterpret_cast<const float4*>(wt + ((long)tap * Cin + c0 + k) * Cout + n0 + n4 * 4);
-    }
-  };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int r = it * (NT / 8) + (tid >> 3);
-      As[(kc + 0) * LDA + r] = ra[it].x;
-      As[(kc + 1) * LDA + r] = ra[it].y;
-      As[(kc + 2) * LDA + r] = ra[it].z;
-      As[(kc + 3) * LDA + r] = ra[it].w;
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int idx = it * NT + tid, k = idx / (BN / 4), n4 = idx % (BN / 4);
-      *reinterpret_cast<float4*>(&Bs[k * LDB + n4 * 4]) = rb[it];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) acc[i][j][reg] = 0.f;
-
-  const int csteps = Cin / BK, steps = (tap1 - tap0) * csteps;
-  if (steps > 0) load_tiles(tap0, 0);
-  for (int s = 0; s < steps; ++s) {
-    store_tiles();
-    __syncthreads();
-    if (s + 1 < steps) load_tiles(tap0 + (s + 1) / csteps, ((s + 1) % csteps) * BK);
-    mma_step<TM, TN>(As, Bs, LDA, LDB, wm0, wn0, acc);
-    __syncthreads();
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+#ifdef SFM_TRACE
+#define TR(i) do { if (trace_on && tn < 1020) g_trace[tb + tn++] = clock64(); } while (0)
+  const bool trace_on = lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300);
+  const int tb = (blockIdx.x == 0 ? 0 : 8192) + wave_all * 1024;
+  if (tid == 0 && blockIdx.x < 1024) {
+    g_trace[16384 + blockIdx.x * 4 + 0] = wall_clock64();
+    g_trace[16384 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(63492);                 // HW_ID
+    g_trace[16384 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
   }
-  if constexpr (EP)
-    store_acc<TM, TN>(acc, out, Cout, m0 + wm0, M, n0 + wn0, ep);  // only launched with gridDim.z == 1
-  else
-    store_acc<TM, TN>(acc, out + blockIdx.z * split_stride, Cout, m0 + wm0, M, n0 + wn0);
+#else
+#define TR(i)
+#endif
+
+  // the two roles run the tile loop separately: inside one loop the compiler keeps the loop-invariant address tables of
+  // BOTH roles live in every wave (spills at the 168 registers that 3 waves per SIMD leave)
+  if (loader) {
+    __builtin_amdgcn_s_setprio(3);
+    for (long u = u0; u < u1;) {
+      const long t = u / K;
+      const int kb = (int)(u - t * K), ke = (int)((long)K < kb + (u1 - u) ? (long)K : kb + (u1 - u));
+      const long tm = t / ntn;
+      const long m0 = tm * BM;
+      const int n0 = (int)(t - tm * ntn) * BN;
+      const int steps = ke - kb;
+  #ifdef SFM_TRACE
+      int tn = 0;
+  #endif
+      // A: instruction q of this wave fills rows (wave * A_IT + q) * 8 .. + 8; this lane: row + (lane >> 3), slot lane & 7.
+      // Everything a lane needs per K-step is a byte offset and the 9 tap-validity bits of its pixel: the loaders share
+      // their SIMD's VALU port with the multipliers' MFMAs and get about one instruction in per MFMA (64 cycles), so
+      // the ~15 VALU instructions per DMA of the plain form (coordinates, bounds, 64-bit address) made the loaders the
+      // critical path (5-7 K cycles of issue per step against 4.4 K of MFMAs)
+      long aoff[A_IT];
+      unsigned vmask[A_IT];
+      {
+        const int row0 = wave * A_IT * 8 + (lane >> 3);
+        const unsigned hw = (unsigned)H * (unsigned)W, mm = (unsigned)(m0 + row0);
+        const unsigned rem = mm - (mm / hw) * hw;
+        int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) {
+          const int row = row0 + q * 8;
+          const int kg4 = 4 * ((lane & 7) ^ ((row >> 1) & 7));
+          unsigned mask = 0;
+          if (m0 + row < M) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+              const int yy = y + (tp / 3 - 1) * rate, xx = x + (tp % 3 - 1) * rate;
+              mask |= (unsigned)(yy >= 0 && yy < H && xx >= 0 && xx < W) << tp;
+            }
+          }
+          vmask[q] = mask;
+          aoff[q] = ((m0 + row) * Cin + kg4) * 4;
+          x += 8;  // the next instruction's row: 8 pixels on
+          while (x >= W) { x -= W; ++y; }
+          while (y >= H) y -= H;
+        }
+      }
+      auto issue = [&](int g, float* As) __attribute__((always_inline)) {  // K-step g of the tile -> tile buffer As
+        const int tap = g / csteps, c0 = (g - tap * csteps) * BK;
+        const int dy = (tap / 3 - 1) * rate, dx = (tap % 3 - 1) * rate;
+        const char* abase = reinterpret_cast<const char*>(in) + ((long)(dy * W + dx) * Cin + c0) * 4;  // uniform
+        const char* bbase = reinterpret_cast<const char*>(wt) + (((long)tap * Cin + c0) * Cout + n0) * 4;
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) {
+          const char* gp = ((vmask[q] >> tap) & 1u) ? abase + aoff[q] : reinterpret_cast<const char*>(g_zero16);
+          __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(As + (wave * A_IT + q) * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q)
+          __builtin_amdgcn_global_load_lds((gptr_t)(bbase + boff[q]), (lptr_t)(As + A_FLOATS + (wave * B_IT + q) * 256), 16, 0, 0);
+      };
+      issue(kb, lds0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      // one barrier per K-step, as in the multiplier loop below; steps taken in pairs so that the buffers are named
+      auto land = [&]() __attribute__((always_inline)) {
+        TR(1);
+        TR(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of the next step has landed ...
+        TR(3);
+        __syncthreads();  // ... and everybody's; the multipliers are done with the other buffer
+      };
+      int s = 0;
+      for (; s + 1 < steps; s += 2) {
+        TR(0);
+        issue(kb + s + 1, lds1);
+        land();
+        TR(0);
+        if (s + 2 < steps) issue(kb + s + 2, lds0);
+        land();
+      }
+      if (s < steps) {
+        TR(0);
+        land();
+      }
+      TR(0);
+      u += steps;
+    }
+    return;
+  }
+  for (long u = u0; u < u1;) {
+    const long t = u / K;
+    const int kb = (int)(u - t * K), ke = (int)((long)K < kb + (u1 - u) ? (long)K : kb + (u1 - u));
+    const long tm = t / ntn;
+    const long m0 = tm * BM;
+    const int n0 = (int)(t - tm * ntn) * BN;
+    const int steps = ke - kb;
+#ifdef SFM_TRACE
+    int tn = 0;
+#endif
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[i][j][reg] = 0.f;
+
+    // one K-step on a landed buffer: the operands of k-group c + 1 are requested before the 4 x TM x TN MFMAs of group
+    // c (sched_barrier pins the order: the scheduler otherwise sinks every ds_read to just in front of its first use)
+    struct Frag {
+      float4 a[TM];
+      float b[4][TN];
+    };
+    auto fetch = [&](const float* As, int c, Frag& f) __attribute__((always_inline)) {
+      const float* Bs = As + A_FLOATS;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = wm0 + i * 32 + r;
+        f.a[i] = *reinterpret_cast<const float4*>(As + (m * 8 + ((2 * c + h) ^ ((m >> 1) & 7))) * 4);
+      }
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j4][j] = Bs[(8 * c + 4 * h + j4) * BN + wn0 + j * 32 + r];
+    };
+    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float a = j4 == 0 ? f.a[i].x : (j4 == 1 ? f.a[i].y : (j4 == 2 ? f.a[i].z : f.a[i].w));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[j4][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto compute = [&](const float* As) __attribute__((always_inline)) {
+      Frag f0, f1;
+      fetch(As, 0, f0);
+#pragma unroll
+      for (int c = 0; c < BK / 8; c += 2) {
+        fetch(As, c + 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < BK / 8) fetch(As, c + 2, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    __syncthreads();
+    auto step = [&](const float* As) __attribute__((always_inline)) {
+      TR(0);
+      TR(1);
+      compute(As);
+      TR(2);
+      TR(3);
+      __syncthreads();  // the loaders' DMA of the next step has landed; everybody is done reading this buffer
+    };
+    int s = 0;
+    for (; s + 1 < steps; s += 2) {
+      step(lds0);
+      step(lds1);
+    }
+    if (s < steps) step(lds0);
+    TR(0);
+    // (opaque copies: the compiler otherwise forms the 64 row addresses of the store in front of the K-loop and
+    // spills them across it)
+    int lane_o = lane, wm0_o = wm0;
+    asm volatile("" : "+v"(lane_o), "+s"(wm0_o));
+    if (kb == 0 && ke == K) {  // the whole tile: straight to the output
+      if constexpr (EP) store_acc<TM, TN>(acc, out, Cout, m0 + wm0_o, M, n0 + wn0, ep, lane_o);
+      else store_acc<TM, TN>(acc, out, Cout, m0 + wm0_o, M, n0 + wn0, Epilogue{nullptr, nullptr, 0}, lane_o);
+    } else {  // part of a tile: this workgroup's head (slab 0: the range starts inside the tile) or tail (slab 1)
+      float* slab = partial + (wg * 2 + (u == u0 ? 0 : 1)) * (BM * BN);
+      store_acc<TM, TN>(acc, slab, BN, wm0_o, BM, wn0, Epilogue{nullptr, nullptr, 0}, lane_o);
+    }
+    u += steps;
+  }
+#ifdef SFM_TRACE
+  if (tid == 0 && blockIdx.x < 1024) g_trace[16384 + blockIdx.x * 4 + 1] = wall_clock64();
+#endif
+}
+
+// out tile = sum of the slabs of the workgroups whose ranges cut the tile, in workgroup order.  grid (tiles, BM * BN / 4 / 256).
+template <int BM, int BN>
+__global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __restrict__ partial, float* __restrict__ out, long M,
+                                                               int Cout, int K, long nwg, Epilogue ep) {
+  const long t = blockIdx.x;
+  const int ntn = Cout / BN;
+  const long total = ((M + BM - 1) / BM) * ntn * K;
+  const long ta = t * K, tb = ta + K;
+  long w = ta * nwg / total;  // a workgroup at or before the owner of unit ta
+  while (w > 0 && sk_first_unit(w, total, nwg) > ta) --w;
+  while (sk_first_unit(w + 1, total, nwg) <= ta) ++w;
+  {
+    const long a0 = sk_first_unit(w, total, nwg), a1 = sk_first_unit(w + 1, total, nwg);
+    if (a0 <= ta && a1 >= tb) return;  // one workgroup did the whole tile and stored it itself
+  }
+  const long tm = t / ntn;
+  const long m0 = tm * BM;
+  const int n0 = (int)(t - tm * ntn) * BN;
+  const int e = blockIdx.y * kBlock + threadIdx.x;  // float4 of the tile
+  const int row = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (; w < nwg; ++w) {
+    const long a0 = sk_first_unit(w, total, nwg);
+    if (a0 >= tb) break;
+    const long seg0 = a0 > ta ? a0 : ta;
+    const float4 v = *reinterpret_cast<const float4*>(partial + ((w * 2 + (seg0 == a0 ? 0 : 1)) * (long)(BM * BN)) + (long)row * BN + c4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (m0 + row >= M) return;
+  if (ep.scale) {
+    const float4 sc = *reinterpret_cast<const float4*>(ep.scale + n0 + c4), sh = *reinterpret_cast<const float4*>(ep.shift + n0 + c4);
+    s = make_float4(ep_apply(s.x, sc.x, sh.x, ep.act), ep_apply(s.y, sc.y, sh.y, ep.act), ep_apply(s.z, sc.z, sh.z, ep.act),
+                    ep_apply(s.w, sc.w, sh.w, ep.act));
+  }
+  *reinterpret_cast<float4*>(out + (m0 + row) * Cout + n0 + c4) = s;
 }
 
 // ------------------------------------------------------------------ backward weight
@@ -442,29 +650,20 @@ __global__ __launch_bounds__(kBlock) void aspp_flip_kernel(const float* __restri
 struct ConvPlan {
   int cfg;      // 0: 128x128, 1: 256x64, 2: 256x32
   int bm, bn;
-  int splits;   // over taps
-  int tps;      // taps per split
+  long nwg;     // workgroups of the stream-K launch
 };
 
-static ConvPlan conv_plan(long M, int Cin, int Cout) {
+constexpr int kSkResident = 512;  // 2 workgroups per CU x 256 CUs
+static ConvPlan conv_plan(long M, int Cin, int Cout, int ntaps) {
   ConvPlan p;
   if (Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
   else if (Cout % 64 == 0) { p.cfg = 1; p.bm = 256; p.bn = 64; }
   else { p.cfg = 2; p.bm = 256; p.bn = 32; }
-  // taps per workgroup.  Model: the fullest CU gets n = ceil(base * splits / 256) workgroups of 9 / splits
-  // taps; up to 3 are co-resident and overlap each other's stalls (measured: one workgroup alone on a CU
-  // runs at ~0.66 of the rate three reach).  A split also writes and re-reads `splits` M x N slabs (~4 TB/s).
-  const long base = ((M + p.bm - 1) / p.bm) * (Cout / p.bn);
-  const double t_tap = 2.0 * p.bm * p.bn * (double)Cin / (0.6 * 157.3e12 / 256.0);
-  double best = 1e30;
-  p.splits = 1;
-  for (int sp : {1, 3, 9}) {
-    const long n = (base * sp + 255) / 256;
-    const double eff = n >= 3 ? 1.0 : (n == 2 ? 0.9 : 0.66);
-    const double t = (double)n * (9 / sp) * t_tap / eff + (sp > 1 ? 2.0 * sp * (double)M * Cout * 4.0 / 4.0e12 : 0.0);
-    if (t < best * 0.97) { best = t; p.splits = sp; }
-  }
-  p.tps = 9 / p.splits;
+  const long total = ((M + p.bm - 1) / p.bm) * (Cout / p.bn) * ntaps * (Cin / BK);
+  // one resident set of workgroups with equal ranges; small problems: at least 4 K-steps per workgroup
+  static const long forced = [] { const char* e = getenv("SFM_ASPP_NWG"); return e ? atol(e) : 0L; }();  // experiments
+  const long resident = forced > 0 ? forced : kSkResident;
+  p.nwg = total / 4 < resident ? (total / 4 > 0 ? total / 4 : 1) : resident;
   return p;
 }
 
@@ -504,7 +703,7 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, int rate, in
 
 static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
   return B > 0 && H > 0 && W > 0 && rate > 0 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0 &&
-         (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 40);
+         (long)B * H * W < (1L << 31) && (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 40);
 }
 
 // ntaps = 9: the dilated 3x3; ntaps = 1: a 1x1 convolution = the same kernels on the centre tap alone (rate 0 makes every
@@ -512,20 +711,20 @@ static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
 static int launch_conv(const float* in, const float* wt, float* out, float* slabs, int B, int H, int W, int Cin, int Cout,
                        int rate, hipStream_t stream, int ntaps = 9, Epilogue ep = Epilogue{nullptr, nullptr, 0}) {
   const long M = (long)B * H * W;
-  ConvPlan p = conv_plan(M, Cin, Cout);
-  if (ntaps == 1) { p.splits = 1; p.tps = 1; rate = 0; }
-  float* dst = p.splits > 1 ? slabs : out;
-  const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), Cout / p.bn, p.splits);
-  const long stride = M * Cout;
-  const Epilogue kep = p.splits > 1 ? Epilogue{nullptr, nullptr, 0} : ep;  // split taps: the slab reduction applies it
-#define SFM_CONV_LAUNCH(...)                                                                                            \
+  const ConvPlan p = conv_plan(M, Cin, Cout, ntaps);
+  if (ntaps == 1) rate = 0;
+  const int K = ntaps * (Cin / BK);
+  const long tiles = ((M + p.bm - 1) / p.bm) * (Cout / p.bn);
+#define SFM_CONV_LAUNCH(BM_, BN_, WM_, WN_)                                                                              \
   do {                                                                                                                  \
-    if (kep.scale)                                                                                                      \
-      hipLaunchKernelGGL((aspp_conv_kernel<__VA_ARGS__, true>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin, Cout, \
-                         rate, p.tps, stride, kep);                                                                     \
+    if (ep.scale)                                                                                                       \
+      hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, true>), dim3((unsigned)p.nwg), dim3(conv_threads(BM_, BN_, WM_, WN_)), 0, stream, in, wt, \
+                         out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                              \
     else                                                                                                                \
-      hipLaunchKernelGGL((aspp_conv_kernel<__VA_ARGS__, false>), grid, dim3(256), 0, stream, in, wt, dst, B, H, W, Cin,  \
-                         Cout, rate, p.tps, stride, kep);                                                               \
+      hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false>), dim3((unsigned)p.nwg), dim3(conv_threads(BM_, BN_, WM_, WN_)), 0, stream, in,    \
+                         wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                          \
+    hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), 0,     \
+                       stream, slabs, out, M, Cout, K, p.nwg, ep);                                                      \
   } while (0)
   if (p.cfg == 0)
     SFM_CONV_LAUNCH(128, 128, 64, 64);
@@ -534,10 +733,6 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
   else
     SFM_CONV_LAUNCH(256, 32, 64, 32);
 #undef SFM_CONV_LAUNCH
-  if (p.splits > 1) {
-    const long n4 = stride / 4;
-    launch_reduce(slabs, n4, p.splits, out, stream, Cout, ep);
-  }
   return sfm_last_error();
 }
 
@@ -564,10 +759,11 @@ using namespace sfm;
 extern "C" long long sfm_aspp_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout) {
   if (!conv_dims_ok(B, H, W, Cin, Cout, 1)) return SFM_ERR_ARG;
   const long M = (long)B * H * W;
-  const ConvPlan f = conv_plan(M, Cin, Cout), d = conv_plan(M, Cout, Cin);
+  const ConvPlan f = conv_plan(M, Cin, Cout, 9), d = conv_plan(M, Cout, Cin, 9);
   const WgradPlan g = wgrad_plan(B, H, W, Cin, Cout, 1), g2 = wgrad_plan(B, H, W, Cin, Cout, kSegMaxRate + 1);
-  const long fwd = f.splits > 1 ? (long)f.splits * M * Cout : 0;
-  const long bwd = (d.splits > 1 ? (long)d.splits * M * Cin : 0) + 9L * Cin * Cout;
+  // stream-K slabs: two partial tiles per workgroup (the 1x1 convolutions launch at most as many workgroups)
+  const long fwd = 2L * f.nwg * f.bm * f.bn;
+  const long bwd = 2L * d.nwg * d.bm * d.bn + 9L * Cin * Cout;
   const long wg = (long)(g.splits > g2.splits ? g.splits : g2.splits) * 9 * Cin * Cout;  // either weight-gradient kernel
   long n = fwd > bwd ? fwd : bwd;
   if (wg > n) n = wg;
