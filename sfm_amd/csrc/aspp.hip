@@ -116,6 +116,18 @@ extern "C" int sfm_debug_trace(long long* out) { return (int)hipMemcpyFromSymbol
 // the same range ~8 % sooner; handing it 25/24 or 26/24 of the mean made every layer slower, profiles/r02_aspp_kloop.txt.)
 __host__ __device__ inline long sk_first_unit(long w, long total, long nwg) { return w * total / nwg; }
 
+// Wave roles.  A DMA instruction that has to be issued while the SIMD's matrix pipe is busy waits for it: beside two
+// waves of back-to-back MFMAs one global_load_lds took 600-900 cycles to issue against ~110 beside the same loop with
+// the MFMAs replaced by v_fma (cycle stamps, tools/trace_conv.py; profiles/r02_aspp_kloop.txt).  With every wave doing
+// both jobs the issue block (8 DMAs, 1100-2400 cycles) sat in front of each wave's MFMAs, the two workgroups of a CU
+// drifted into the same phase, and a second workgroup per CU bought nothing (171 us at 256 and at 512 workgroups);
+// dealing the DMAs between the MFMAs was slower still.  So a workgroup has NW multiplier waves, which never touch
+// global memory inside the K-loop, and NW loader waves that do nothing else (one of each per SIMD and workgroup,
+// 4 waves per SIMD with the CU's second workgroup: 128 registers each): the loaders crawl while the multipliers run
+// and finish in the gap before the barrier, 171 -> 150 us per convolution.  The loaders' per-step VALU work is cut to
+// an add and a select per DMA (byte offsets and tap-validity bits are formed once per tile).
+constexpr int conv_threads(int bm, int bn, int wm, int wn) { return (bm / wm) * (bn / wn) * 64 * 2; }
+
 template <int BM, int BN, int WM, int WN, bool EP>
 __global__ __launch_bounds__(conv_threads(BM, BN, WM, WN)) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out,
