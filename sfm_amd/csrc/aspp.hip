@@ -361,12 +361,12 @@ void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__
 }
 
 // out tile = sum of the slabs of the workgroups whose ranges cut the tile, in workgroup order.  grid (tiles, BM * BN / 4 / 256).
-template <int BM, int BN>
+// WGRAD: a "tile" is a (ci tile, co tile, tap) block of the weight gradient, K its pixel steps, rows = Cin, taps = ntaps.
+template <int BM, int BN, bool WGRAD>
 __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __restrict__ partial, float* __restrict__ out, long M,
-                                                               int Cout, int K, long nwg, Epilogue ep) {
+                                                               int Cout, int K, long nwg, long total, int taps, Epilogue ep) {
   const long t = blockIdx.x;
   const int ntn = Cout / BN;
-  const long total = ((M + BM - 1) / BM) * ntn * K;
   const long ta = t * K, tb = ta + K;
   long w = ta * nwg / total;  // a workgroup at or before the owner of unit ta
   while (w > 0 && sk_first_unit(w, total, nwg) > ta) --w;
@@ -375,9 +375,6 @@ __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __re
     const long a0 = sk_first_unit(w, total, nwg), a1 = sk_first_unit(w + 1, total, nwg);
     if (a0 <= ta && a1 >= tb) return;  // one workgroup did the whole tile and stored it itself
   }
-  const long tm = t / ntn;
-  const long m0 = tm * BM;
-  const int n0 = (int)(t - tm * ntn) * BN;
   const int e = blockIdx.y * kBlock + threadIdx.x;  // float4 of the tile
   const int row = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -388,13 +385,166 @@ __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __re
     const float4 v = *reinterpret_cast<const float4*>(partial + ((w * 2 + (seg0 == a0 ? 0 : 1)) * (long)(BM * BN)) + (long)row * BN + c4);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  if (m0 + row >= M) return;
+  long orow;  // row of the [rows][Cout] output matrix
+  int n0;
+  if constexpr (WGRAD) {
+    const long tile = t / taps;
+    const int tap = (int)(t - tile * taps);
+    orow = (long)tap * M + (tile / ntn) * BM + row;  // M = Cin here
+    n0 = (int)(tile % ntn) * BN;
+  } else {
+    const long tm = t / ntn;
+    orow = tm * BM + row;
+    n0 = (int)(t - tm * ntn) * BN;
+    if (orow >= M) return;
+  }
   if (ep.scale) {
     const float4 sc = *reinterpret_cast<const float4*>(ep.scale + n0 + c4), sh = *reinterpret_cast<const float4*>(ep.shift + n0 + c4);
     s = make_float4(ep_apply(s.x, sc.x, sh.x, ep.act), ep_apply(s.y, sc.y, sh.y, ep.act), ep_apply(s.z, sc.z, sh.z, ep.act),
                     ep_apply(s.w, sc.w, sh.w, ep.act));
   }
-  *reinterpret_cast<float4*>(out + (m0 + row) * Cout + n0 + c4) = s;
+  *reinterpret_cast<float4*>(out + orow * Cout + n0 + c4) = s;
+}
+
+// ------------------------------------------------------------------ backward weight, stream-K + LDS-DMA + loader waves
+// The same machinery for dL/dw[tap][ci][co] = sum_p in[p + tap offset][ci] * gout[p][co]: M = Cin, N = Cout, K = the
+// B*H*W pixels in steps of 32.  Both operands lie K-major in memory ([pixel][channel]), so both tiles are dense
+// [BK][BM] / [BK][BN] LDS images filled by 1 KB DMA pieces and read with ds_read_b32 (lane (r, h): row k + h, word r).
+// A unit = one K-step of one (ci tile, co tile, tap) block; 512 workgroups take equal contiguous ranges (the old grid
+// of blocks x taps x pixel splits left 416-576 workgroups for 512-1024 slots: CUs with 2 and CUs with 3).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(conv_threads(BM, BN, WM, WN)) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void aspp_wgrad_sk_kernel(const float* __restrict__ in, const float* __restrict__ gout, float* __restrict__ gw,
+                          float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps) {
+  constexpr int NW = (BM / WM) * (BN / WN), NL = NW;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BN;
+  constexpr int A_IT = A_FLOATS / 256 / NL, B_IT = B_FLOATS / 256 / NL;
+  static_assert(A_IT >= 1 && B_IT >= 1 && A_FLOATS % (256 * NL) == 0 && B_FLOATS % (256 * NL) == 0, "tile / wave mismatch");
+  __shared__ __attribute__((aligned(1024))) float lds0[A_FLOATS + B_FLOATS];
+  __shared__ __attribute__((aligned(1024))) float lds1[A_FLOATS + B_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave_all >= NW;
+  const int wave = loader ? wave_all - NW : wave_all;
+  const int wm0 = (wave % (BM / WM)) * WM, wn0 = (wave / (BM / WM)) * WN;
+  const long M = (long)B * H * W;
+  const int K = (int)((M + BK - 1) / BK), ntn = Cout / BN;
+  const long total = (long)(Cin / BM) * ntn * ntaps * K;
+  const long wg = gridDim.x % 8 == 0 ? (long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (long)blockIdx.x;
+  const long u0 = sk_first_unit(wg, total, gridDim.x), u1 = sk_first_unit(wg + 1, total, gridDim.x);
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  if (loader) {
+    __builtin_amdgcn_s_setprio(3);
+    // lane constants: row k and byte offset of its 16 bytes inside a K-step's A / B block
+    int ak[A_IT], aoff[A_IT], bk_[B_IT], boff[B_IT];
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) {
+      const int f = (wave * A_IT + q) * 256 + lane * 4;
+      ak[q] = f / BM;
+      aoff[q] = (ak[q] * Cin + f % BM) * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) {
+      const int f = (wave * B_IT + q) * 256 + lane * 4;
+      bk_[q] = f / BN;
+      boff[q] = (bk_[q] * Cout + f % BN) * 4;
+    }
+    for (long u = u0; u < u1;) {
+      const long t = u / K;
+      const int kb = (int)(u - t * K), ke = (int)((long)K < kb + (u1 - u) ? (long)K : kb + (u1 - u));
+      const long tile = t / ntaps;
+      const int tap = (int)(t - tile * ntaps);
+      const int ci0 = (int)(tile / ntn) * BM, co0 = (int)(tile % ntn) * BN;
+      const int dy = (tap / 3 - 1) * rate, dx = (tap % 3 - 1) * rate;
+      const int steps = ke - kb;
+      // image coordinates of this lane's pixel of each A instruction, advanced by BK pixels per step
+      int ay[A_IT], ax[A_IT];
+#pragma unroll
+      for (int q = 0; q < A_IT; ++q) {
+        const unsigned hw = (unsigned)H * (unsigned)W, pp = (unsigned)((long)kb * BK + ak[q]);
+        const unsigned rem = pp % hw;
+        ay[q] = (int)(rem / (unsigned)W);
+        ax[q] = (int)(rem - (unsigned)ay[q] * (unsigned)W);
+      }
+      const char* abase0 = reinterpret_cast<const char*>(in) + ((long)(dy * W + dx) * Cin + ci0) * 4;
+      const char* bbase0 = reinterpret_cast<const char*>(gout) + (long)co0 * 4;
+      auto issue = [&](int g, float* As) __attribute__((always_inline)) {  // K-step g -> tile buffer As
+        const char* abase = abase0 + (long)g * BK * Cin * 4;
+        const char* bbase = bbase0 + (long)g * BK * Cout * 4;
+        const long left = M - (long)g * BK;  // pixels from the step's first one to the end
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) {
+          const int y = ay[q] + dy, x = ax[q] + dx;
+          const bool ok = ak[q] < left && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+          const char* gp = ok ? abase + aoff[q] : reinterpret_cast<const char*>(g_zero16);
+          __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(As + (wave * A_IT + q) * 256), 16, 0, 0);
+          ax[q] += BK;
+          while (ax[q] >= W) { ax[q] -= W; ++ay[q]; }
+          while (ay[q] >= H) ay[q] -= H;
+        }
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) {
+          const char* gp = bk_[q] < left ? bbase + boff[q] : reinterpret_cast<const char*>(g_zero16);
+          __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(As + A_FLOATS + (wave * B_IT + q) * 256), 16, 0, 0);
+        }
+      };
+      auto land = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      };
+      issue(kb, lds0);
+      land();
+      int s = 0;
+      for (; s + 1 < steps; s += 2) {
+        issue(kb + s + 1, lds1);
+        land();
+        if (s + 2 < steps) issue(kb + s + 2, lds0);
+        land();
+      }
+      if (s < steps) land();
+      u += steps;
+    }
+    return;
+  }
+  for (long u = u0; u < u1;) {
+    const long t = u / K;
+    const int kb = (int)(u - t * K), ke = (int)((long)K < kb + (u1 - u) ? (long)K : kb + (u1 - u));
+    const int steps = ke - kb;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[i][j][reg] = 0.f;
+    __syncthreads();
+    int s = 0;
+    for (; s + 1 < steps; s += 2) {
+      mma_step<TM, TN>(lds0, lds0 + A_FLOATS, BM, BN, wm0, wn0, acc);
+      __syncthreads();
+      mma_step<TM, TN>(lds1, lds1 + A_FLOATS, BM, BN, wm0, wn0, acc);
+      __syncthreads();
+    }
+    if (s < steps) {
+      mma_step<TM, TN>(lds0, lds0 + A_FLOATS, BM, BN, wm0, wn0, acc);
+      __syncthreads();
+    }
+    int lane_o = lane, wm0_o = wm0;
+    asm volatile("" : "+v"(lane_o), "+s"(wm0_o));
+    if (kb == 0 && ke == K) {
+      const long tile = t / ntaps;
+      const int tap = (int)(t - tile * ntaps);
+      const int ci0 = (int)(tile / ntn) * BM, co0 = (int)(tile % ntn) * BN;
+      store_acc<TM, TN>(acc, gw + (long)tap * Cin * Cout, Cout, ci0 + wm0_o, Cin, co0 + wn0, Epilogue{nullptr, nullptr, 0}, lane_o);
+    } else {
+      float* slab = partial + (wg * 2 + (u == u0 ? 0 : 1)) * (BM * BN);
+      store_acc<TM, TN>(acc, slab, BN, wm0_o, BM, wn0, Epilogue{nullptr, nullptr, 0}, lane_o);
+    }
+    u += steps;
+  }
 }
 
 // ------------------------------------------------------------------ backward weight
@@ -698,9 +848,15 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, int rate, in
     p.splits = (int)((nsteps + p.pps - 1) / p.pps);
     return p;
   }
-  if (Cin % 128 == 0 && Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
-  else if (Cin % 128 == 0 && Cout % 64 == 0) { p.cfg = 1; p.bm = 128; p.bn = 64; }
-  else if (Cin % 64 == 0) { p.cfg = 2; p.bm = 64; p.bn = 32; }
+  if (Cin % 128 == 0 && Cout % 64 == 0) {  // stream-K kernels: splits = 0, pps = workgroups
+    const bool wide = Cout % 128 == 0;
+    p.cfg = wide ? 0 : 1; p.bm = 128; p.bn = wide ? 128 : 64;
+    const long total = (long)(Cin / p.bm) * (Cout / p.bn) * ntaps * ((M + BK - 1) / BK);
+    p.splits = 0;
+    p.pps = total / 4 < kSkResident ? (total / 4 > 0 ? total / 4 : 1) : kSkResident;
+    return p;
+  }
+  if (Cin % 64 == 0) { p.cfg = 2; p.bm = 64; p.bn = 32; }
   else { p.cfg = 3; p.bm = 32; p.bn = 32; }
   const long base = (long)(Cin / p.bm) * (Cout / p.bn) * ntaps;
   long splits = (512 + base - 1) / base;
@@ -735,8 +891,8 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
     else                                                                                                                \
       hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false>), dim3((unsigned)p.nwg), dim3(conv_threads(BM_, BN_, WM_, WN_)), 0, stream, in,    \
                          wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                          \
-    hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), 0,     \
-                       stream, slabs, out, M, Cout, K, p.nwg, ep);                                                      \
+    hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, false>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
+                       0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, 1, ep);                                     \
   } while (0)
   if (p.cfg == 0)
     SFM_CONV_LAUNCH(128, 128, 64, 64);
@@ -776,7 +932,8 @@ extern "C" long long sfm_aspp_conv3x3_workspace_floats(int B, int H, int W, int 
   // stream-K slabs: two partial tiles per workgroup (the 1x1 convolutions launch at most as many workgroups)
   const long fwd = 2L * f.nwg * f.bm * f.bn;
   const long bwd = 2L * d.nwg * d.bm * d.bn + 9L * Cin * Cout;
-  const long wg = (long)(g.splits > g2.splits ? g.splits : g2.splits) * 9 * Cin * Cout;  // either weight-gradient kernel
+  long wg = (long)(g.splits > g2.splits ? g.splits : g2.splits) * 9 * Cin * Cout;  // either split weight-gradient kernel
+  if (g.splits == 0) wg = 2L * g.pps * g.bm * g.bn;                                 // stream-K slabs
   long n = fwd > bwd ? fwd : bwd;
   if (wg > n) n = wg;
   n = (n + 3) & ~3L;
@@ -823,19 +980,30 @@ static int launch_wgrad(const float* in, const float* gout, int B, int H, int W,
                         float* ws, hipStream_t stream, int ntaps) {
   if (ntaps == 1) rate = 0;
   const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout, rate, ntaps);
-  float* dst = p.splits > 1 ? ws : gw;
+  float* dst = p.splits > 1 ? ws : gw;  // (stream-K plans: splits = 0, the slabs live in ws)
   const dim3 grid((Cin / p.bm) * (Cout / p.bn), ntaps, p.splits);
   if (p.cfg == 4) {
     const size_t lds = (size_t)(3 * (BK + 2 * rate) * 68 + BK * 36) * sizeof(float);
     hipLaunchKernelGGL(aspp_wgrad9_kernel, dim3((Cin / 64) * (Cout / 32), p.splits), dim3(192), lds, stream, in, gout, dst, B, H,
                        W, Cin, Cout, rate, p.pps);
-  } else if (p.cfg == 0)
-    hipLaunchKernelGGL((aspp_wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
-                       rate, p.pps);
-  else if (p.cfg == 1)
-    hipLaunchKernelGGL((aspp_wgrad_kernel<128, 64, 64, 32>), grid, dim3(256), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
-                       rate, p.pps);
-  else if (p.cfg == 2)
+  } else if (p.cfg == 0 || p.cfg == 1) {
+    const long M = (long)B * H * W;
+    const int K = (int)((M + BK - 1) / BK);
+    const long tiles = (long)(Cin / p.bm) * (Cout / p.bn) * ntaps;
+    const Epilogue none{nullptr, nullptr, 0};
+    if (p.cfg == 0) {
+      hipLaunchKernelGGL((aspp_wgrad_sk_kernel<128, 128, 64, 64>), dim3((unsigned)p.pps), dim3(conv_threads(128, 128, 64, 64)), 0,
+                         stream, in, gout, gw, ws, B, H, W, Cin, Cout, rate, ntaps);
+      hipLaunchKernelGGL((aspp_sk_fixup_kernel<128, 128, true>), dim3((unsigned)tiles, 128 * 128 / 4 / kBlock), dim3(kBlock), 0,
+                         stream, ws, gw, (long)Cin, Cout, K, p.pps, tiles * K, ntaps, none);
+    } else {
+      hipLaunchKernelGGL((aspp_wgrad_sk_kernel<128, 64, 64, 32>), dim3((unsigned)p.pps), dim3(conv_threads(128, 64, 64, 32)), 0,
+                         stream, in, gout, gw, ws, B, H, W, Cin, Cout, rate, ntaps);
+      hipLaunchKernelGGL((aspp_sk_fixup_kernel<128, 64, true>), dim3((unsigned)tiles, 128 * 64 / 4 / kBlock), dim3(kBlock), 0,
+                         stream, ws, gw, (long)Cin, Cout, K, p.pps, tiles * K, ntaps, none);
+    }
+    return sfm_last_error();
+  } else if (p.cfg == 2)
     hipLaunchKernelGGL((aspp_wgrad_kernel<64, 32, 32, 32>), grid, dim3(128), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
                        rate, p.pps);
   else
