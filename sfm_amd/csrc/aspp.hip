@@ -360,11 +360,18 @@ void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__
 #endif
 }
 
-// out tile = sum of the slabs of the workgroups whose ranges cut the tile, in workgroup order.  grid (tiles, BM * BN / 4 / 256).
+// out tile = sum of the slabs of the workgroups whose ranges cut the tile, in a fixed order (bitwise reproducible).
 // WGRAD: a "tile" is a (ci tile, co tile, tap) block of the weight gradient, K its pixel steps, rows = Cin, taps = ntaps.
-template <int BM, int BN, bool WGRAD>
+// WIDE = false: grid (tiles, BM * BN / 4 / 256), a thread owns a float4 and adds the slabs in workgroup order - the
+//   convolutions, where a tile is cut by a handful of ranges.
+// WIDE = true: grid (tiles, BM * BN / 4 / 16), 16 float4 per block, 16 thread groups each add every 16th slab and LDS
+//   combines the groups in group order - weight gradients of few tiles, where hundreds of ranges cut one tile (a 1x1
+//   convolution 128 -> 64 is ONE tile cut by all 512 workgroups: the serial form took 105 us for it, longer than the
+//   MFMA kernel).
+template <int BM, int BN, bool WGRAD, bool WIDE>
 __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __restrict__ partial, float* __restrict__ out, long M,
                                                                int Cout, int K, long nwg, long total, int taps, Epilogue ep) {
+  __shared__ float4 red[WIDE ? 16 : 1][16];
   const long t = blockIdx.x;
   const int ntn = Cout / BN;
   const long ta = t * K, tb = ta + K;
@@ -375,15 +382,25 @@ __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __re
     const long a0 = sk_first_unit(w, total, nwg), a1 = sk_first_unit(w + 1, total, nwg);
     if (a0 <= ta && a1 >= tb) return;  // one workgroup did the whole tile and stored it itself
   }
-  const int e = blockIdx.y * kBlock + threadIdx.x;  // float4 of the tile
+  const int grp = WIDE ? threadIdx.x >> 4 : 0, ngrp = WIDE ? 16 : 1;
+  const int e = WIDE ? blockIdx.y * 16 + (threadIdx.x & 15) : blockIdx.y * kBlock + threadIdx.x;  // float4 of the tile
   const int row = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (; w < nwg; ++w) {
+  for (w += grp; w < nwg; w += ngrp) {
     const long a0 = sk_first_unit(w, total, nwg);
     if (a0 >= tb) break;
     const long seg0 = a0 > ta ? a0 : ta;
     const float4 v = *reinterpret_cast<const float4*>(partial + ((w * 2 + (seg0 == a0 ? 0 : 1)) * (long)(BM * BN)) + (long)row * BN + c4);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if constexpr (WIDE) {
+    red[grp][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = red[k][threadIdx.x & 15];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
   long orow;  // row of the [rows][Cout] output matrix
   int n0;
@@ -891,7 +908,7 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
     else                                                                                                                \
       hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false>), dim3((unsigned)p.nwg), dim3(conv_threads(BM_, BN_, WM_, WN_)), 0, stream, in,    \
                          wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                          \
-    hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, false>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
+    hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, false, false>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
                        0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, 1, ep);                                     \
   } while (0)
   if (p.cfg == 0)
@@ -991,17 +1008,23 @@ static int launch_wgrad(const float* in, const float* gout, int B, int H, int W,
     const int K = (int)((M + BK - 1) / BK);
     const long tiles = (long)(Cin / p.bm) * (Cout / p.bn) * ntaps;
     const Epilogue none{nullptr, nullptr, 0};
-    if (p.cfg == 0) {
-      hipLaunchKernelGGL((aspp_wgrad_sk_kernel<128, 128, 64, 64>), dim3((unsigned)p.pps), dim3(conv_threads(128, 128, 64, 64)), 0,
-                         stream, in, gout, gw, ws, B, H, W, Cin, Cout, rate, ntaps);
-      hipLaunchKernelGGL((aspp_sk_fixup_kernel<128, 128, true>), dim3((unsigned)tiles, 128 * 128 / 4 / kBlock), dim3(kBlock), 0,
-                         stream, ws, gw, (long)Cin, Cout, K, p.pps, tiles * K, ntaps, none);
-    } else {
-      hipLaunchKernelGGL((aspp_wgrad_sk_kernel<128, 64, 64, 32>), dim3((unsigned)p.pps), dim3(conv_threads(128, 64, 64, 32)), 0,
-                         stream, in, gout, gw, ws, B, H, W, Cin, Cout, rate, ntaps);
-      hipLaunchKernelGGL((aspp_sk_fixup_kernel<128, 64, true>), dim3((unsigned)tiles, 128 * 64 / 4 / kBlock), dim3(kBlock), 0,
-                         stream, ws, gw, (long)Cin, Cout, K, p.pps, tiles * K, ntaps, none);
-    }
+    const bool wide = p.pps > 8 * tiles;  // more than ~8 ranges cut a tile
+#define SFM_WGRAD_LAUNCH(BM_, BN_, WM_, WN_)                                                                                  \
+  do {                                                                                                                        \
+    hipLaunchKernelGGL((aspp_wgrad_sk_kernel<BM_, BN_, WM_, WN_>), dim3((unsigned)p.pps), dim3(conv_threads(BM_, BN_, WM_, WN_)), \
+                       0, stream, in, gout, gw, ws, B, H, W, Cin, Cout, rate, ntaps);                                         \
+    if (wide)                                                                                                                 \
+      hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, true, true>), dim3((unsigned)tiles, BM_ * BN_ / 4 / 16), dim3(kBlock),  \
+                         0, stream, ws, gw, (long)Cin, Cout, K, p.pps, tiles * K, ntaps, none);                               \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, true, false>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock),           \
+                         dim3(kBlock), 0, stream, ws, gw, (long)Cin, Cout, K, p.pps, tiles * K, ntaps, none);                 \
+  } while (0)
+    if (p.cfg == 0)
+      SFM_WGRAD_LAUNCH(128, 128, 64, 64);
+    else
+      SFM_WGRAD_LAUNCH(128, 64, 64, 32);
+#undef SFM_WGRAD_LAUNCH
     return sfm_last_error();
   } else if (p.cfg == 2)
     hipLaunchKernelGGL((aspp_wgrad_kernel<64, 32, 32, 32>), grid, dim3(128), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
