@@ -301,6 +301,25 @@ int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float*
                    const float* save_invstd, long long M, int C, int act, float* gx, float* ggamma, float* gbeta,
                    float* ws, void* stream);
 
+/* The same batch norm with its statistics taken over ALL ranks of a data-parallel job (the batch of
+ * SfMLearner_uni.py:36-45 sharded over GPUs; the reference is single-device, so this is its graph on the global
+ * batch).  The collectives stay with the caller (torch.distributed over RCCL):
+ *   forward : sfm_bn_local_stats -> all-gather of stats -> sfm_bn_elu_apply_stats
+ *   backward: sfm_bn_elu_bwd_sums -> all-reduce (sum) of ggamma / gbeta copies -> sfm_bn_elu_bwd_apply
+ * stats [3][C] fp64 = (row count, mean, sum of squared deviations) of this rank's M rows; stats_all [world][3][C] =
+ * the gathered triples, merged in rank order (Chan's update: identical on every rank).  sfm_bn_elu_bwd_sums returns
+ * this rank's share of dL/dgamma, dL/dbeta (to be summed over ranks with the other parameter gradients);
+ * sfm_bn_elu_bwd_apply takes the sums over all ranks and the global row count.  ws as sfm_bn_elu_fwd. */
+int sfm_bn_local_stats(const float* x, long long M, int C, double* stats, float* ws, void* stream);
+int sfm_bn_elu_apply_stats(const float* x, const float* gamma, const float* beta, const double* stats_all, int world,
+                           long long M, int C, float eps, double decay, int act, float* moving_mean, float* moving_var,
+                           float* y, float* save_mean, float* save_invstd, void* stream);
+int sfm_bn_elu_bwd_sums(const float* x, const float* y, const float* gy, const float* save_mean, const float* save_invstd,
+                        long long M, int C, int act, float* ggamma, float* gbeta, float* ws, void* stream);
+int sfm_bn_elu_bwd_apply(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
+                         const float* save_invstd, const float* ggamma_all, const float* gbeta_all, long long M,
+                         long long M_global, int C, int act, float* gx, void* stream);
+
 /* ---- snippet unpack, augmentation and preprocessing (data_loader.py) ---------------
  * seq: the decoded uint8 snippets [B, H, (n_src+1) W, 3] exactly as tf.image.decode_jpeg returns the files
  * data/prepare_train_data.py:47 writes (frames side by side), already in device memory; K [B,3,3] from the

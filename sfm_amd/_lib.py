@@ -76,6 +76,10 @@ SIGNATURES = {
     "sfm_bn_elu_workspace_floats": [_LL, _I],
     "sfm_bn_elu_fwd": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P, _P],
     "sfm_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P],
+    "sfm_bn_local_stats": [_P, _LL, _I, _P, _P, _P],
+    "sfm_bn_elu_apply_stats": [_P, _P, _P, _P, _I, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P],
+    "sfm_bn_elu_bwd_sums": [_P, _P, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P],
+    "sfm_bn_elu_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _LL, _I, _I, _P, _P],
     "sfm_snippet_workspace_floats": [_I, _I, _I, _I],
     "sfm_snippet_unpack": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P, _P],
     "sfm_prof_enable": [_I],

@@ -132,12 +132,80 @@ class _BatchNormElu(torch.autograd.Function):
         return gx, ggamma, gbeta, None, None, None, None, None
 
 
+class _SyncBatchNormElu(torch.autograd.Function):
+    """batch norm + ELU with statistics over all ranks of ``group``: all-gather of (n, mean, M2) per channel in the
+    forward, all-reduce of (sum dz xhat, sum dz) in the backward - two small collectives per layer and direction."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, decay, epsilon, act, group, stats_override):
+        import torch.distributed as dist
+        C = x.shape[-1]
+        M = x.numel() // C
+        lib = _lib.load()
+        n_ws = lib.sfm_bn_elu_workspace_floats(M, C)
+        if n_ws < 0:
+            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4, at most 1024)")
+        with torch.cuda.device(x.device):
+            ws = torch.empty(n_ws // 2 + 1, dtype=torch.float64, device=x.device)
+            if stats_override is None:
+                world = dist.get_world_size(group)
+                stats_all = torch.empty(world, 3, C, dtype=torch.float64, device=x.device)
+                mine = stats_all[dist.get_rank(group)]
+                call("sfm_bn_local_stats", ptr(x), M, C, ptr(mine), ptr(ws), stream_of(x))
+                dist.all_gather_into_tensor(stats_all.view(-1), mine.reshape(-1).clone(), group=group)
+            else:  # (tests: the gathered triples of a rehearsed world, computed by the caller)
+                stats_all = stats_override.contiguous()
+                world = stats_all.shape[0]
+            y = torch.empty_like(x)
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            call("sfm_bn_elu_apply_stats", ptr(x), ptr(gamma), ptr(beta), ptr(stats_all), world, M, C, float(epsilon),
+                 float(decay), int(act), ptr(moving_mean), ptr(moving_var), ptr(y), ptr(mean), ptr(invstd), stream_of(x))
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.beta_ref = beta if beta.data_ptr() in _grad_sinks else None
+        ctx.act, ctx.group = int(act), group
+        ctx.m_global = int(round(float(stats_all[:, 0, 0].sum())))
+        ctx.rehearsed = stats_override is not None
+        ctx.mark_non_differentiable(mean, invstd)
+        return y, mean, invstd
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gi):
+        import torch.distributed as dist
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        C = x.shape[-1]
+        M = x.numel() // C
+        gy = gy.contiguous()
+        with torch.cuda.device(x.device):
+            ws = torch.empty(_lib.load().sfm_bn_elu_workspace_floats(M, C) // 2 + 1, dtype=torch.float64, device=x.device)
+            gx = torch.empty_like(x)
+            ggamma = _grad_out(gamma)
+            gbeta = _grad_out(ctx.beta_ref) if ctx.beta_ref is not None else torch.empty_like(gamma)
+            call("sfm_bn_elu_bwd_sums", ptr(x), ptr(y), ptr(gy), ptr(mean), ptr(invstd), M, C, ctx.act, ptr(ggamma), ptr(gbeta),
+                 ptr(ws), stream_of(x))
+            both = torch.stack([ggamma, gbeta])  # a copy: the local sums stay this rank's parameter gradients
+            if ctx.rehearsed:
+                if _SyncBatchNormElu.rehearsal_sums is None:
+                    raise RuntimeError("rehearsed backward without rehearsal_sums")
+                both = _SyncBatchNormElu.rehearsal_sums(both)
+            else:
+                dist.all_reduce(both, group=ctx.group)
+            call("sfm_bn_elu_bwd_apply", ptr(x), ptr(y), ptr(gy), ptr(gamma), ptr(mean), ptr(invstd), ptr(both[0]), ptr(both[1]),
+                 M, ctx.m_global, C, ctx.act, ptr(gx), stream_of(x))
+        return gx, ggamma, gbeta, None, None, None, None, None, None, None
+
+    rehearsal_sums = None  # tests: callable mapping this "rank"'s [2, C] sums to the sums over the rehearsed world
+
+
 def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor = None, moving_var: Tensor = None,
-                   decay: float = BN_DECAY, epsilon: float = BN_EPSILON, activation: bool = True) -> Tensor:
+                   decay: float = BN_DECAY, epsilon: float = BN_EPSILON, activation: bool = True,
+                   process_group=None, _stats_all: Tensor = None) -> Tensor:
     """``tf.nn.elu(slim.batch_norm(x, decay, epsilon, scale=True, fused=True, is_training=True,
     updates_collections=None))`` - the normaliser + activation of the ASPP arg-scope (nets.py:653-656).
     x [..., C] NHWC; gamma, beta [C]; moving_mean / moving_var [C] are updated in place when given.
-    ``activation=False``: the batch norm alone (``slim.conv2d(..., activation_fn=None)``, nets.py:455, 470)."""
+    ``activation=False``: the batch norm alone (``slim.conv2d(..., activation_fn=None)``, nets.py:455, 470).
+    ``process_group``: statistics over the batches of ALL ranks of the group (synchronised batch norm: the
+    single-device graph on the global batch); default ``None`` = this rank's batch only."""
     x = _check(x, "x", x.dim() if isinstance(x, torch.Tensor) else 4)
     C = x.shape[-1]
     gamma = _check(gamma, "gamma", 1, C)
@@ -148,18 +216,22 @@ def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor =
             if not t.is_contiguous():
                 raise ValueError(f"{name} is updated in place: it must be contiguous")
     _same_device(x, gamma, beta, moving_mean, moving_var)
+    if process_group is not None or _stats_all is not None:
+        return _SyncBatchNormElu.apply(x, gamma, beta, moving_mean, moving_var, float(decay), float(epsilon), bool(activation),
+                                       process_group, _stats_all)[0]
     return _BatchNormElu.apply(x, gamma, beta, moving_mean, moving_var, float(decay), float(epsilon), bool(activation))[0]
 
 
 def conv2d_bn_elu(x: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, rate: int, moving_mean: Tensor = None,
                   moving_var: Tensor = None, decay: float = BN_DECAY, epsilon: float = BN_EPSILON,
-                  is_training: bool = True, activation: bool = True) -> Tensor:
+                  is_training: bool = True, activation: bool = True, process_group=None) -> Tensor:
     """One ``slim.conv2d(x, Cout, [3, 3], rate=rate)`` of ``disp_bottleneck_dense`` under its arg-scope
     (nets.py:457, 458, 463): dilated convolution (no bias: a normaliser is set), batch norm, ELU.
     ``is_training=False`` (the inference graphs, test_kitti_depth_con.py:19-65): batch norm on the moving statistics
     and the ELU are applied where the MFMA kernel stores its sums - one pass, forward only."""
     if is_training:
-        return batch_norm_elu(dilated_conv3x3(x, w, rate), gamma, beta, moving_mean, moving_var, decay, epsilon, activation)
+        return batch_norm_elu(dilated_conv3x3(x, w, rate), gamma, beta, moving_mean, moving_var, decay, epsilon, activation,
+                              process_group=process_group)
     x = _check(x, "x", 4)
     w = _check(w, "w", 4)
     if w.shape[0] != 3 or w.shape[1] != 3 or w.shape[2] != x.shape[3]:
@@ -220,39 +292,44 @@ def conv1x1(x: Tensor, w: Tensor) -> Tensor:
     return _Conv1x1.apply(x, w)
 
 
-def _slim_conv(x, p, name, rate=None, activation=True):
+def _slim_conv(x, p, name, rate=None, activation=True, process_group=None):
     """one slim.conv2d of the block under its arg-scope: p[name] = dict(w, gamma, beta[, moving_mean, moving_var])"""
     q = p[name]
     y = conv1x1(x, q["w"]) if rate is None else dilated_conv3x3(x, q["w"], rate)
-    return batch_norm_elu(y, q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"), activation=activation)
+    return batch_norm_elu(y, q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"), activation=activation,
+                          process_group=process_group)
 
 
 def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None, rates=(2, 4), use_skip: bool = True,
-                          use_skip2: bool = True, skip2: Tensor = None):
+                          use_skip2: bool = True, skip2: Tensor = None, process_group=None):
     """``nets.disp_bottleneck_dense`` (nets.py:451-471), one decoder level of ``disp_aspp_u_dense``, every op a
     hand-written kernel: x2 bilinear upsample, 1x1 and dilated 3x3 convolutions on fp32 MFMA, batch norm (training) +
     ELU; ``torch.cat`` only moves data.  ``params``: name -> dict(w, gamma, beta[, moving_mean, moving_var]) for
     'up' (:455), 'sup' (:456), 'aspp_up' (:457), 'aspp_up2' (:458), 'skip' (:461 or :463), ['skip2' (:466)], 'out'
     (:470) and, with use_skip, 'skip_bn' = dict(gamma, beta, ...) for the batch norm of the skip feature (:460).
-    ``skip_feat`` = end_points[skip_block].  Returns (xconcat, upnet) like the reference."""
+    ``skip_feat`` = end_points[skip_block].  Returns (xconcat, upnet) like the reference.  ``process_group``: every
+    batch norm of the block takes its statistics over all ranks of the group (see ``batch_norm_elu``)."""
     from .pyramid import resize_bilinear
+    import functools
+    conv = functools.partial(_slim_conv, process_group=process_group)
     h, w = concat.shape[1], concat.shape[2]
     upnet = resize_bilinear(concat, 2 * h, 2 * w)                                        # :454
-    upnet = _slim_conv(upnet, params, "up", activation=False)                            # :455
-    supnet = _slim_conv(upnet, params, "sup")                                            # :456
-    aspp_up = _slim_conv(upnet, params, "aspp_up", rate=rates[0])                        # :457
-    aspp_up2 = _slim_conv(torch.cat([supnet, aspp_up], dim=3), params, "aspp_up2", rate=rates[1])   # :458
+    upnet = conv(upnet, params, "up", activation=False)                            # :455
+    supnet = conv(upnet, params, "sup")                                            # :456
+    aspp_up = conv(upnet, params, "aspp_up", rate=rates[0])                        # :457
+    aspp_up2 = conv(torch.cat([supnet, aspp_up], dim=3), params, "aspp_up2", rate=rates[1])   # :458
     if use_skip:
         q = params["skip_bn"]
-        skip = batch_norm_elu(skip_feat, q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"))   # :460
-        skip = _slim_conv(skip, params, "skip")                                          # :461
+        skip = batch_norm_elu(skip_feat, q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"),
+                              process_group=process_group)                               # :460
+        skip = conv(skip, params, "skip")                                          # :461
     else:
-        skip = _slim_conv(torch.cat([aspp_up, aspp_up2], dim=3), params, "skip", rate=rates[1] * 2)   # :463
+        skip = conv(torch.cat([aspp_up, aspp_up2], dim=3), params, "skip", rate=rates[1] * 2)   # :463
     parts = [supnet, aspp_up, aspp_up2, skip]
     if use_skip2:
         s2 = resize_bilinear(skip2, 2 * h, 2 * w)                                        # :465
-        parts.append(_slim_conv(s2, params, "skip2"))                                    # :466
-    xconcat = _slim_conv(torch.cat(parts, dim=3), params, "out", activation=False)       # :470
+        parts.append(conv(s2, params, "skip2"))                                    # :466
+    xconcat = conv(torch.cat(parts, dim=3), params, "out", activation=False)       # :470
     return xconcat, upnet
 
 

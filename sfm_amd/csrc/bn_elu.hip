@@ -125,6 +125,49 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_fwd_kernel(const double* _
   }
 }
 
+// ---- synchronised statistics (data parallel): a rank publishes (n, mean, M2) per channel in fp64, the
+// ranks' triples are gathered and every rank merges them in RANK ORDER with Chan's pairwise update - the same numbers on
+// every rank, exact up to fp64 rounding whatever the ranks' own means are (no common shift needed).
+__global__ __launch_bounds__(kBlock) void bn_local_stats_kernel(const double* __restrict__ part, const float* __restrict__ x,
+                                                                long M, int C, int chunks, double* __restrict__ stats) {
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s, q;
+  bn_chunk_sums(part, C, chunks, c, s, q);
+  if ((threadIdx.x & 63) != 0) return;
+  stats[c] = (double)M;
+  stats[C + c] = (double)x[c] + s / (double)M;
+  stats[2 * C + c] = fmax(q - s * s / (double)M, 0.0);
+}
+
+// stats [world][3][C] -> batch statistics over all ranks (and the moving averages, as bn_finalize_fwd_kernel)
+__global__ __launch_bounds__(kBlock) void bn_merge_stats_kernel(const double* __restrict__ stats, int world, int C, float eps,
+                                                                float one_minus_decay, float* __restrict__ moving_mean,
+                                                                float* __restrict__ moving_var,
+                                                                float* __restrict__ save_mean,
+                                                                float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= C) return;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double* sr = stats + (size_t)r * 3 * C;
+    const double nb = sr[c], mb = sr[C + c], m2b = sr[2 * C + c];
+    if (!(nb > 0.0)) continue;
+    const double nn = n + nb, delta = mb - mean;
+    mean += delta * (nb / nn);
+    m2 += m2b + delta * delta * (n * nb / nn);
+    n = nn;
+  }
+  const double var = n > 0.0 ? m2 / n : 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (moving_mean) moving_mean[c] = moving_mean[c] - (moving_mean[c] - (float)mean) * one_minus_decay;
+  if (moving_var) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    moving_var[c] = moving_var[c] - (moving_var[c] - (float)unbiased) * one_minus_decay;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void bn_finalize_bwd_kernel(const double* __restrict__ part, int C, int chunks,
                                                                  float* __restrict__ ggamma, float* __restrict__ gbeta) {
   const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -235,5 +278,69 @@ extern "C" int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, c
   const long n4 = (long)M * p.groups;
   hipLaunchKernelGGL(bn_elu_bwd_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, y, gy,
                      gamma, save_mean, save_invstd, ggamma, gbeta, n4, p.groups, (float)(1.0 / (double)M), act, gx);
+  return sfm_last_error();
+}
+
+// ---- the same batch norm with statistics over ALL ranks of a data-parallel job (no counterpart in the reference, which is
+// single-device: this IS its graph when the global batch is sharded).  The collectives stay with the caller:
+//   sfm_bn_local_stats  -> all-gather of stats [3][C] fp64  -> sfm_bn_elu_apply_stats          (forward)
+//   sfm_bn_elu_bwd_sums -> all-reduce (sum) of the two [C] vectors -> sfm_bn_elu_bwd_apply     (backward)
+// stats = (row count, mean, sum of squared deviations) per channel of this rank's M rows.
+extern "C" int sfm_bn_local_stats(const float* x, long long M, int C, double* stats, float* ws, void* stream_) {
+  BnPlan p;
+  if (!x || !stats || !ws || !bn_plan((long)M, C, p) || ((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks), dim3(kBlock), 0, stream, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
+  hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, x, (long)M, C, p.chunks, stats);
+  return sfm_last_error();
+}
+
+// stats_all [world][3][C]: the gathered triples, rank-major.  Writes y and the merged save_mean / save_invstd.
+extern "C" int sfm_bn_elu_apply_stats(const float* x, const float* gamma, const float* beta, const double* stats_all, int world,
+                                      long long M, int C, float eps, double decay, int act, float* moving_mean,
+                                      float* moving_var, float* y, float* save_mean, float* save_invstd, void* stream_) {
+  BnPlan p;
+  if (!x || !gamma || !beta || !stats_all || world < 1 || !y || !save_mean || !save_invstd || !bn_plan((long)M, C, p) ||
+      !(eps > 0.0f))
+    return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(bn_merge_stats_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, stats_all, world, C, eps,
+                     (float)(1.0 - decay), moving_mean, moving_var, save_mean, save_invstd);
+  const long n4 = (long)M * p.groups;
+  hipLaunchKernelGGL(bn_elu_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, gamma, beta,
+                     save_mean, save_invstd, n4, p.groups, act, y);
+  return sfm_last_error();
+}
+
+// this rank's (sum dz xhat, sum dz) = its share of dL/dgamma, dL/dbeta
+extern "C" int sfm_bn_elu_bwd_sums(const float* x, const float* y, const float* gy, const float* save_mean,
+                                   const float* save_invstd, long long M, int C, int act, float* ggamma, float* gbeta,
+                                   float* ws, void* stream_) {
+  BnPlan p;
+  if (!x || !y || !gy || !save_mean || !save_invstd || !ggamma || !gbeta || !ws || !bn_plan((long)M, C, p) ||
+      ((uintptr_t)ws & 7) != 0)
+    return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
+                     p, act, part);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma, gbeta);
+  return sfm_last_error();
+}
+
+// gx from the sums over ALL ranks (ggamma_all, gbeta_all: the all-reduced vectors) and the global row count
+extern "C" int sfm_bn_elu_bwd_apply(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, const float* ggamma_all, const float* gbeta_all, long long M,
+                                    long long M_global, int C, int act, float* gx, void* stream_) {
+  BnPlan p;
+  if (!x || !y || !gy || !gamma || !save_mean || !save_invstd || !ggamma_all || !gbeta_all || !gx || M_global < M ||
+      !bn_plan((long)M, C, p))
+    return SFM_ERR_ARG;
+  const long n4 = (long)M * p.groups;
+  hipLaunchKernelGGL(bn_elu_bwd_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
+                     x, y, gy, gamma, save_mean, save_invstd, ggamma_all, gbeta_all, n4, p.groups,
+                     (float)(1.0 / (double)M_global), act, gx);
   return sfm_last_error();
 }

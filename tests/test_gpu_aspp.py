@@ -118,6 +118,61 @@ def test_batch_norm_elu_matches_oracle(dev, shape):
     assert rel_err(mm_g, mm_o) <= 1e-5
 
 
+@pytest.mark.parametrize("C,split", [(64, (3, 5)), (32, (1, 7)), (256, (4, 4))])
+def test_sync_batch_norm_two_rehearsed_ranks_equal_the_global_batch(dev, C, split):
+    """synchronised batch norm (data parallel): two "ranks" with unequal, differently centred shards -
+    their gathered (n, mean, M2) triples and summed backward sums reproduce the oracle's batch norm of the WHOLE batch"""
+    from sfm_amd import aspp as A
+    from sfm_amd._lib import call, ptr, stream_of
+    from sfm_amd import _lib
+    g = torch.Generator().manual_seed(15)
+    B = sum(split)
+    x = torch.randn(B, 9, 14, C, generator=g) * 1.5 + 0.7
+    x[split[0]:] += 2.0                                     # the second shard's own mean is far from the first's
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    gy = torch.randn(B, 9, 14, C, generator=g)
+    mm_o, mv_o = torch.zeros(C), torch.ones(C)
+    xo, go, bo = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    R.batch_norm_elu(xo, go, bo, mm_o, mv_o).backward(gy)
+
+    shards = [x[:split[0]].contiguous().to(dev), x[split[0]:].contiguous().to(dev)]
+    gys = [gy[:split[0]].contiguous().to(dev), gy[split[0]:].contiguous().to(dev)]
+    stats_all = torch.empty(2, 3, C, dtype=torch.float64, device=dev)
+    for r, xs in enumerate(shards):
+        M = xs.numel() // C
+        ws = torch.empty(_lib.load().sfm_bn_elu_workspace_floats(M, C) // 2 + 1, dtype=torch.float64, device=dev)
+        call("sfm_bn_local_stats", ptr(xs), M, C, ptr(stats_all[r]), ptr(ws), stream_of(xs))
+    ys, leaves, mms, saved = [], [], [], []
+    for r, xs in enumerate(shards):
+        xr, gr, br = xs.requires_grad_(True), gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+        mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        y, mean, invstd = A._SyncBatchNormElu.apply(xr, gr, br, mm, mv, A.BN_DECAY, A.BN_EPSILON, True, None, stats_all)
+        ys.append(y); leaves.append((xr, gr, br)); mms.append((mm, mv)); saved.append((mean, invstd))
+    assert rel_err(torch.cat(ys), R.batch_norm_elu(x, gamma, beta)) <= 1e-5
+    for mm, mv in mms:                                      # every rank holds the global moving statistics
+        assert rel_err(mm, mm_o) <= 1e-5 and rel_err(mv, mv_o) <= 1e-5
+    assert torch.equal(saved[0][0], saved[1][0]) and torch.equal(saved[0][1], saved[1][1])
+    # the all-reduce of the backward sums, rehearsed: every shard's local sums first, then their total for each backward
+    local = []
+    for r, xs in enumerate(shards):
+        M = xs.numel() // C
+        ws = torch.empty(_lib.load().sfm_bn_elu_workspace_floats(M, C) // 2 + 1, dtype=torch.float64, device=dev)
+        gg, gb = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        call("sfm_bn_elu_bwd_sums", ptr(xs), ptr(ys[r].detach()), ptr(gys[r]), ptr(saved[r][0]), ptr(saved[r][1]), M, C, 1, ptr(gg),
+             ptr(gb), ptr(ws), stream_of(xs))
+        local.append(torch.stack([gg, gb]))
+    total = local[0] + local[1]
+    A._SyncBatchNormElu.rehearsal_sums = staticmethod(lambda both: total.clone())
+    try:
+        for r in range(2):
+            ys[r].backward(gys[r])
+    finally:
+        A._SyncBatchNormElu.rehearsal_sums = None
+    assert rel_err(torch.cat([leaves[0][0].grad, leaves[1][0].grad]), xo.grad) <= 1e-4
+    assert rel_err(leaves[0][1].grad + leaves[1][1].grad, go.grad) <= 1e-4     # parameter gradients: summed over ranks
+    assert rel_err(leaves[0][2].grad + leaves[1][2].grad, bo.grad) <= 1e-4
+
+
 def test_conv2d_bn_elu_is_one_slim_conv2d(dev):
     """slim.conv2d(x, 64, [3, 3], rate=3) under the ASPP arg-scope = dilated conv -> batch norm -> ELU"""
     g = torch.Generator().manual_seed(6)

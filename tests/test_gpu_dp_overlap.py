@@ -73,3 +73,22 @@ def test_multi_scale_loss_takes_the_overlapped_path_and_matches_the_oracle(dev, 
     assert rel_err(pg.grad, po.grad) <= TOL_GRAD
     for s in range(3):
         assert rel_err(tg[s].grad, to[s].grad) <= TOL_GRAD
+
+
+def test_sync_batch_norm_over_a_one_rank_rccl_group_equals_plain_batch_norm(dev, nccl_world1):
+    """batch_norm_elu(process_group=...): the all-gather / all-reduce path itself, on a 1-rank RCCL group"""
+    import torch.distributed as dist
+    g = torch.Generator().manual_seed(31)
+    C = 64
+    x = (torch.randn(4, 10, 12, C, generator=g) * 1.3 + 0.4).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+    gy = torch.randn(4, 10, 12, C, generator=g).to(dev)
+    outs = []
+    for pg in (None, dist.group.WORLD):
+        xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        y = sfm_amd.batch_norm_elu(xr, gr, br, mm, mv, process_group=pg)
+        y.backward(gy)
+        outs.append((y.detach(), xr.grad, gr.grad, br.grad, mm, mv))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max() <= 1e-5 * max(1.0, float(b.abs().max()))
