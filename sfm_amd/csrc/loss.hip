@@ -149,11 +149,15 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
         dep = lv.d[p]; t0 = t.x; t1 = t.y; t2 = t.z;
       }
     } else {
-      const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
-      dep = depth[sb + p]; t0 = t.x; t1 = t.y; t2 = t.z;
+      dep = depth[sb + p];
+      t0 = t1 = t2 = 0.0f;
+      if (trans) {  // (null only from the stand-alone splat, add_trans = False)
+        const f3 t = ld3(trans + (sb + p) * C3 + 3 * i);
+        t0 = t.x; t1 = t.y; t2 = t.z;
+      }
     }
     (void)direct;
-    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, true, t0, t1, t2);
+    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, PYR || trans != nullptr, t0, t1, t2);
     // displacement of the clipped landing point (what the corners are clipped to); NaNs drop out of fmin / fmax
     lo_x = hi_x = fminf(fmaxf(g.x, 0.0f), xmax) - (float)u;
     lo_y = hi_y = fminf(fmaxf(g.y, 0.0f), ymax) - (float)v;
@@ -175,7 +179,10 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
 }
 
 // grid: tiles_x * tiles_y * S*N*B blocks (1-D), 256 threads.
-template <bool PYR>
+// SOLO = the stand-alone operator (sfm_splat_warp_fwd: one image set, S = N = 1): no gather, `trans` may be null, and Acc
+// IS the zero-initialised side accumulator - the tile is flushed into it with float atomics (one add per element, no
+// contention) because overflow corners of other workgroups land in the same buffer.
+template <bool PYR, bool SOLO = false>
 __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const float* __restrict__ tgt,
                                                                  const float* __restrict__ src,
                                                                  const float* __restrict__ depth,
@@ -259,7 +266,8 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   PyrLevel lv{};
   if constexpr (PYR) lv = pyr_level(pm, s, b, i, C3, d.H, d.W);
   const float* __restrict__ dmap = PYR ? lv.d : depth + sb;                       // a full-size level is read directly
-  const float* __restrict__ tmap = PYR ? lv.t : trans + sb * C3 + 3 * i;
+  const bool has_trans = !SOLO || trans != nullptr;
+  const float* __restrict__ tmap = PYR ? lv.t : (has_trans ? trans + sb * C3 + 3 * i : nullptr);
   const bool lowres = PYR && lv.lowres;  // workgroup-uniform
   // low-resolution level: the four taps of every map are requested here and interpolated when the pixel is processed
   // (one iteration later), like the plain loads - the resize must not put a memory round trip back into the loop
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
         pxl = lx.l; pyl = ly.l;
       } else {
         ndep = dmap[p];
-        nt = ld3(tmap + (size_t)p * C3);
+        if (has_trans) nt = ld3(tmap + (size_t)p * C3);
       }
     }
   };
@@ -301,9 +309,9 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
     if (!ok) continue;
     const bool home = (u >= x0 && u < x1 && v >= y0 && v < y1);
     const int p = v * d.W + u;
-    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, true, t.x, t.y, t.z);
+    const Geom g = geom_fwd(ps, grid_coord(u, step_x, xmax), grid_coord(v, step_y, ymax), dep, has_trans, t.x, t.y, t.z);
     const Corners c = corners(g.x, g.y, xmax, ymax);
-    const bool do_gather = home && i < ng;
+    const bool do_gather = !SOLO && home && i < ng;
     f3 ta{0.f, 0.f, 0.f}, tb = ta, tc = ta, td = ta;
     if (do_gather) {  // the taps of the gather (utils.py:322-325): requested now, used after the atomics
       const float* sbase = src + imgpix * C3 + 3 * i;
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
             atomicAdd(o + 3, sw.g[q]);
             // the DESTINATION tile's flag: only its consumers (stencil strips over it, the backward tile that clears it)
             // pay for the side accumulator.  Plain stores of 1: every racer writes the same value
-            flags[(size_t)img * (tiles_x * tiles_y) + ((unsigned)cy[q] / STH) * tiles_x + (unsigned)cx[q] / STW] = 1;
+            if (!SOLO) flags[(size_t)img * (tiles_x * tiles_y) + ((unsigned)cy[q] / STH) * tiles_x + (unsigned)cx[q] / STW] = 1;
           }
       }
     }
@@ -374,9 +382,19 @@ __global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const fl
   float* __restrict__ accg = Acc + (size_t)img * HW * 4;
   for (int k = threadIdx.x; k < TP; k += kSplatThreads) {
     const int u = x0 + (k & (STW - 1)), v = y0 + (k / STW);
-    if (u < x1 && v < y1)
-      *reinterpret_cast<float4*>(accg + ((size_t)v * d.W + u) * 4) =
-          make_float4((float)acc[k], (float)acc[TP + k], (float)acc[2 * TP + k], (float)acc[3 * TP + k]);
+    if (u < x1 && v < y1) {
+      float* o = accg + ((size_t)v * d.W + u) * 4;
+      if constexpr (SOLO) {
+        if (acc[3 * TP + k] != 0.0) {  // (untouched cells stay zero)
+          atomicAdd(o + 0, (float)acc[k]);
+          atomicAdd(o + 1, (float)acc[TP + k]);
+          atomicAdd(o + 2, (float)acc[2 * TP + k]);
+          atomicAdd(o + 3, (float)acc[3 * TP + k]);
+        }
+      } else {
+        *reinterpret_cast<float4*>(o) = make_float4((float)acc[k], (float)acc[TP + k], (float)acc[2 * TP + k], (float)acc[3 * TP + k]);
+      }
+    }
   }
 }
 
@@ -831,6 +849,27 @@ static inline LossLayout loss_layout(const LossDims& d) {
 
 using namespace sfm;
 
+
+// The forward splat of ONE image set on the tile-owned kernels (warp.hip: sfm_splat_warp_fwd).  acc [B,H,W,4] must be
+// zero on the stream; table: scratch for B * tiles int4 (16-byte aligned).  False = shape not supported here.
+namespace sfm {
+long splat_solo_table_int4s(int B, int H, int W) { return (long)B * ((W + STW - 1) / STW) * ((H + STH - 1) / STH); }
+bool launch_splat_solo(const float* img, const float* depth, const float* trans, const float* params, int B, int H, int W,
+                       float* acc, void* table, hipStream_t stream) {
+  if (B > 65535 || !sfm_fits(H, W, 8)) return false;
+  LossDims d{B, H, W, 1, 1};
+  const int tx = (W + STW - 1) / STW, ty = (H + STH - 1) / STH;
+  const long n = (long)B * tx * ty;
+  int4* shift = reinterpret_cast<int4*>(table);
+  hipLaunchKernelGGL(loss_tile_shift_kernel<false>, dim3((unsigned)((n * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                     depth, trans, PyrMaps{}, params, d, sfm_lin_step(W), sfm_lin_step(H), tx, ty, shift, kReachAdd, kReachMin,
+                     kReachMax);
+  hipLaunchKernelGGL((loss_splat_tile_kernel<false, true>), dim3((unsigned)n), dim3(kSplatThreads), 0, stream, img,
+                     (const float*)nullptr, depth, trans, PyrMaps{}, params, d, sfm_lin_step(W), sfm_lin_step(H), tx, ty, shift,
+                     (float*)nullptr, acc, acc, (int*)nullptr);
+  return true;
+}
+}  // namespace sfm
 
 extern "C" long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N) {
   LossDims d{B, H, W, S, N};

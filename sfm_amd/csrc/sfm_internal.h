@@ -22,3 +22,10 @@ static inline bool sfm_fits(long h, long w, long per_pixel) { return h * w * per
 int sfm_launch_pose_grad(const float* pose, long pose_sb, long pose_si, const float* K, const float* partials, int n_sets,
                          int nblk, int B, int n_src, int inverse_pose, float gscale, float* d_pose, long dpose_sb,
                          long dpose_si, int* zero, int n_zero, hipStream_t stream);
+
+// loss.hip: the tile-owned LDS splat for one image set (the stand-alone projective_warp forward)
+namespace sfm {
+long splat_solo_table_int4s(int B, int H, int W);
+bool launch_splat_solo(const float* img, const float* depth, const float* trans, const float* params, int B, int H, int W,
+                       float* acc, void* table, hipStream_t stream);
+}

@@ -9,6 +9,8 @@
 // count, scalar loop).  One thread per target pixel, blockIdx.y = batch item so the
 // 21 pose/intrinsics constants are scalar loads.  HBM-bound: no LDS staging is needed
 // here because every tensor element is touched once and taps hit L2.
+#include <cstdint>
+#include <cstdlib>
 #include "sfm_device.h"
 #include "sfm_internal.h"
 
@@ -116,27 +118,59 @@ __global__ __launch_bounds__(kBlock) void sampler_bwd_kernel(CoordSrc cs, const 
   const float xmax = (float)(Ws - 1), ymax = (float)(Hs - 1);
   const float* ib = img + (long)b * Hs * Ws * C;
   float* dib = d_img ? d_img + (long)b * Hs * Ws * C : nullptr;
+  // (whole waves run every iteration - kBlock * kPPT pixels per block, lanes beyond the image only skip their
+  // loads and stores - so that the lane exchange below always has its neighbour)
   for (int it = 0; it < kPPT; ++it) {
-    const int p = (blockIdx.x * kPPT + it) * kBlock + threadIdx.x;
-    if (p >= Ht * Wt) break;
+    const int p_raw = (blockIdx.x * kPPT + it) * kBlock + threadIdx.x;
+    if ((blockIdx.x * kPPT + it) * kBlock >= Ht * Wt) break;  // block-uniform
+    const bool live = p_raw < Ht * Wt;
+    const int p = live ? p_raw : Ht * Wt - 1;
     Pix px = fetch<GEOM>(cs, ps, b, p, Ht, Wt);
     Corners c = corners(px.x, px.y, xmax, ymax);
     float wx0 = c.fx1 - px.x, wx1 = px.x - c.fx0, wy0 = c.fy1 - px.y, wy1 = px.y - c.fy0;
     const int i00 = c.y0 * Ws + c.x0, i01 = c.y1 * Ws + c.x0, i10 = c.y0 * Ws + c.x1, i11 = c.y1 * Ws + c.x1;
     const long gi = (long)b * Ht * Wt + p;
     float gx_ = 0.0f, gy_ = 0.0f;
+    // d_img: wave-aggregated scatter.  For a smooth warp lane l's right-hand taps (x1, y0 / y1) are lane l + 1's
+    // left-hand ones: a lane hands the contributions of its right column to the next lane when the addresses agree
+    // (one DPP wave shift each way for the test, one per value) and issues atomics only for what it keeps - half the
+    // atomics of the per-lane form on such warps, the same sums in any case.
+    bool keep10 = live, keep11 = live, take00 = false, take01 = false;
+#ifndef SFM_NO_DIMG_MERGE
+    if (dib) {
+      const int lane = threadIdx.x & 63;
+      const int m00 = live ? i00 : -1, m01 = live ? i01 : -1, m10 = live ? i10 : -2, m11 = live ? i11 : -2;
+      const int prev10 = __builtin_amdgcn_update_dpp(-3, m10, 0x138, 0xf, 0xf, false);  // wave_shr:1 - lane l reads l - 1
+      const int prev11 = __builtin_amdgcn_update_dpp(-3, m11, 0x138, 0xf, 0xf, false);
+      const int next00 = __builtin_amdgcn_update_dpp(-4, m00, 0x130, 0xf, 0xf, false);  // wave_shl:1 - lane l reads l + 1
+      const int next01 = __builtin_amdgcn_update_dpp(-4, m01, 0x130, 0xf, 0xf, false);
+      take00 = lane > 0 && prev10 == m00;
+      take01 = lane > 0 && prev11 == m01;
+      keep10 = live && !(lane < 63 && next00 == m10);
+      keep11 = live && !(lane < 63 && next01 == m11);
+    }
+#endif
     for (int ch = 0; ch < (CT == 3 ? 3 : C); ++ch) {
-      float g = gout[gi * C + ch];
+      float g = live ? gout[gi * C + ch] : 0.0f;
       float a = ib[i00 * C + ch], bb = ib[i01 * C + ch], cc = ib[i10 * C + ch], dd = ib[i11 * C + ch];
       gx_ += g * (wy0 * (cc - a) + wy1 * (dd - bb));
       gy_ += g * (wx0 * (bb - a) + wx1 * (dd - cc));
       if (dib) {
-        atomicAdd(dib + i00 * C + ch, (wx0 * wy0) * g);
-        atomicAdd(dib + i01 * C + ch, (wx0 * wy1) * g);
-        atomicAdd(dib + i10 * C + ch, (wx1 * wy0) * g);
-        atomicAdd(dib + i11 * C + ch, (wx1 * wy1) * g);
+        const float v10 = (wx1 * wy0) * g, v11 = (wx1 * wy1) * g;
+        float v00 = (wx0 * wy0) * g, v01 = (wx0 * wy1) * g;
+        const float p10 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v10), 0x138, 0xf, 0xf, false));
+        const float p11 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v11), 0x138, 0xf, 0xf, false));
+        if (take00) v00 += p10;
+        if (take01) v01 += p11;
+        if (live) {
+          atomicAdd(dib + i00 * C + ch, v00);
+          atomicAdd(dib + i01 * C + ch, v01);
+        }
+        if (keep10) atomicAdd(dib + i10 * C + ch, v10);
+        if (keep11) atomicAdd(dib + i11 * C + ch, v11);
       }
     }
+    if (!live) continue;
     if constexpr (GEOM) {
       float dd_, dt0, dt1, dt2;
       geom_bwd(ps, px.g, px.d, cs.trans != nullptr, px.t0, px.t1, px.t2, gx_, gy_, 0.0f, dd_, dt0, dt1, dt2, dp);
@@ -209,6 +243,34 @@ __global__ __launch_bounds__(kBlock) void splat_mask_kernel(const float* __restr
       for (int xx = x0; xx <= x1; ++xx) s += (ob[(yy * W + xx) * C + ch] == 0.0f) ? 0.0f : 1.0f;
     mask[((long)b * H * W + p) * C + ch] = s / cnt;
   }
+}
+
+// out and mask of the C = 3 splat in one pass over the accumulator: out = S / (D + 1e-10) of the pixel, mask = the 3x3
+// SAME average of [out != 0] with the neighbours' quotients recomputed from their accumulators (L2 hits) - the separate
+// normalise and mask kernels read `out` back from memory.
+__global__ __launch_bounds__(kBlock) void splat_finish3_kernel(const float* __restrict__ acc, int H, int W,
+                                                               float* __restrict__ out, float* __restrict__ mask) {
+  const int b = blockIdx.y, p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= H * W) return;
+  const int v = p / W, u = p - v * W;
+  const float4* ab = reinterpret_cast<const float4*>(acc) + (long)b * H * W;
+  const int y0 = max(v - 1, 0), y1 = min(v + 1, H - 1), x0 = max(u - 1, 0), x1 = min(u + 1, W - 1);
+  const float cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+  f3 mine{0.f, 0.f, 0.f};
+  for (int yy = y0; yy <= y1; ++yy)
+    for (int xx = x0; xx <= x1; ++xx) {
+      const float4 a = ab[yy * W + xx];
+      const float den = a.w + 1e-10f;
+      const float o0 = a.x / den, o1 = a.y / den, o2 = a.z / den;
+      s0 += (o0 == 0.0f) ? 0.0f : 1.0f;
+      s1 += (o1 == 0.0f) ? 0.0f : 1.0f;
+      s2 += (o2 == 0.0f) ? 0.0f : 1.0f;
+      if (yy == v && xx == u) mine = f3{o0, o1, o2};
+    }
+  const long gi = (long)b * H * W + p;
+  st3(out + gi * 3, mine.x, mine.y, mine.z);
+  st3(mask + gi * 3, s0 / cnt, s1 / cnt, s2 / cnt);
 }
 
 // ---------------------------------------------------------------- splat backward
@@ -348,6 +410,16 @@ static int splat_fwd_common(bool geom, CoordSrc cs, const float* img, int B, int
   hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * H * W * (C + 1) * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   dim3 grid((H * W + kBlock - 1) / kBlock, B);
+  // projective_warp itself (geometry in registers, RGB, depth-weighted): the tile-owned LDS splat of the fused loss -
+  // workgroups own 64x32 destination tiles and accumulate in LDS, global atomics only for the tile flush and the rare
+  // corner no owner scans.  Its scan-window table lives in `mask`, which is not written before the last kernel.
+  static const bool tile_owned = [] { const char* e = getenv("SFM_SPLAT_TILE"); return !e || e[0] != '0'; }();  // 0: experiments
+  if (tile_owned && geom && C == 3 && use_depth && ((uintptr_t)mask & 15) == 0 && ((uintptr_t)acc & 15) == 0 &&
+      splat_solo_table_int4s(B, H, W) * 4 <= (long)B * H * W * 3 &&
+      launch_splat_solo(img, cs.depth, cs.trans, cs.params, B, H, W, acc, mask, stream)) {
+    hipLaunchKernelGGL(splat_finish3_kernel, grid, dim3(kBlock), 0, stream, acc, H, W, out, mask);
+    return sfm_last_error();
+  }
   if (geom)
     SFM_DISPATCH_C(splat_fwd_kernel, true, C, cs, img, H, W, C, use_depth, acc);
   else
