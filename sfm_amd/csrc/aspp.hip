@@ -128,19 +128,27 @@ __host__ __device__ inline long sk_first_unit(long w, long total, long nwg) { re
 // an add and a select per DMA (byte offsets and tap-validity bits are formed once per tile).
 constexpr int conv_threads(int bm, int bn, int wm, int wn) { return (bm / wm) * (bn / wn) * 64 * 2; }
 
-template <int BM, int BN, int WM, int WN, bool EP>
-__global__ __launch_bounds__(conv_threads(BM, BN, WM, WN)) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// STAGES = 2: NW multiplier + NW loader waves, two tile buffers, 2 workgroups per CU (4 waves per SIMD).
+// STAGES = 3: the 256x128 tile - 8 multiplier + 4 loader waves, three tile buffers (144 KB of LDS), ONE workgroup per CU
+//   (3 waves per SIMD).  A third fewer DMA instructions per FLOP than two 128x128 workgroups (48 against 64 per 8192
+//   MFMA cycles of a SIMD), and the loaders run two steps ahead: s_waitcnt vmcnt(n) with the newest step's n DMAs still
+//   in flight, so a step's landing time is covered by a whole step of MFMAs.
+template <int BM, int BN, int WM, int WN, bool EP, int STAGES = 2>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 + (STAGES == 3 ? 256 : (BM / WM) * (BN / WN) * 64))
+__attribute__((amdgpu_waves_per_eu(STAGES == 3 ? 3 : 4, STAGES == 3 ? 3 : 4)))
 void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out,
                          float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps, Epilogue ep) {
-  constexpr int NW = (BM / WM) * (BN / WN), NL = NW;  // multiplier waves, loader waves
+  constexpr int NW = (BM / WM) * (BN / WN), NL = STAGES == 3 ? 4 : NW;  // multiplier waves, loader waves
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN;
   constexpr int A_IT = A_FLOATS / 256 / NL, B_IT = B_FLOATS / 256 / NL;  // DMA instructions per loader wave and K-step
   static_assert(A_IT >= 1 && B_IT >= 1 && A_FLOATS % (256 * NL) == 0 && B_FLOATS % (256 * NL) == 0, "tile / wave mismatch");
-  // two tile buffers as two DISTINCT arrays: the compiler orders an LDS read behind every LDS-DMA it cannot prove
-  // disjoint (s_waitcnt vmcnt(0) in front of the first ds_read), and only distinct __shared__ objects carry that proof
-  __shared__ __attribute__((aligned(1024))) float lds0[A_FLOATS + B_FLOATS];
-  __shared__ __attribute__((aligned(1024))) float lds1[A_FLOATS + B_FLOATS];
+  static_assert(STAGES == 2 || STAGES == 3, "two or three tile buffers");
+  // (no wave both issues LDS-DMA and reads LDS, so the compiler's rule - every LDS read waits for every LDS-DMA it
+  // cannot prove disjoint - never bites: one array holds all the tile buffers)
+  __shared__ __attribute__((aligned(1024))) float lds_all[STAGES * (A_FLOATS + B_FLOATS)];
+  float* const lds0 = lds_all;
+  float* const lds1 = lds_all + (A_FLOATS + B_FLOATS);
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave_all >= NW;
@@ -234,6 +242,38 @@ void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__
         for (int q = 0; q < B_IT; ++q)
           __builtin_amdgcn_global_load_lds((gptr_t)(bbase + boff[q]), (lptr_t)(As + A_FLOATS + (wave * B_IT + q) * 256), 16, 0, 0);
       };
+      if constexpr (STAGES == 3) {
+        // two steps ahead: when step s is being multiplied, step s + 1 has landed and step s + 2 is in flight
+        constexpr int NDMA = A_IT + B_IT;
+        issue(kb, lds_all);
+        if (steps > 1) {
+          issue(kb + 1, lds1);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // step 0 has landed
+        int nb = 2;       // buffer of step s + 2
+        for (int s = 0; s < steps; ++s) {
+          TR(0);
+          if (s + 2 < steps) {
+            issue(kb + s + 2, lds_all + nb * (A_FLOATS + B_FLOATS));  // (its last readers passed the barrier of step s - 1)
+            TR(1);
+            TR(2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // step s + 1 has landed
+          } else {
+            TR(1);
+            TR(2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          TR(3);
+          __syncthreads();
+          nb = nb == 2 ? 0 : nb + 1;
+        }
+        TR(0);
+        u += steps;
+        continue;
+      }
       issue(kb, lds0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -335,12 +375,20 @@ void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__
       TR(3);
       __syncthreads();  // the loaders' DMA of the next step has landed; everybody is done reading this buffer
     };
-    int s = 0;
-    for (; s + 1 < steps; s += 2) {
-      step(lds0);
-      step(lds1);
+    if constexpr (STAGES == 3) {
+      int cb = 0;
+      for (int s = 0; s < steps; ++s) {
+        step(lds_all + cb * (A_FLOATS + B_FLOATS));
+        cb = cb == 2 ? 0 : cb + 1;
+      }
+    } else {
+      int s = 0;
+      for (; s + 1 < steps; s += 2) {
+        step(lds0);
+        step(lds1);
+      }
+      if (s < steps) step(lds0);
     }
-    if (s < steps) step(lds0);
     TR(0);
     // (opaque copies: the compiler otherwise forms the 64 row addresses of the store in front of the K-loop and
     // spills them across it)
@@ -827,7 +875,7 @@ __global__ __launch_bounds__(kBlock) void aspp_flip_kernel(const float* __restri
 }
 
 struct ConvPlan {
-  int cfg;      // 0: 128x128, 1: 256x64, 2: 256x32
+  int cfg;      // 0: 128x128, 1: 256x64, 2: 256x32, 3: 256x128 with three tile buffers
   int bm, bn;
   long nwg;     // workgroups of the stream-K launch
 };
@@ -835,13 +883,18 @@ struct ConvPlan {
 constexpr int kSkResident = 512;  // 2 workgroups per CU x 256 CUs
 static ConvPlan conv_plan(long M, int Cin, int Cout, int ntaps) {
   ConvPlan p;
-  if (Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
+  // SFM_ASPP_TILE256=1 selects the 256x128 three-buffer configuration (measured 5-12 % SLOWER than two 128x128 workgroups
+  // per CU on every layer, profiles/r02_aspp_kloop.txt: kept as an experiment, off by default)
+  static const bool wide3 = [] { const char* e = getenv("SFM_ASPP_TILE256"); return e && e[0] == '1'; }();
+  long resident_default = kSkResident;
+  if (Cout % 128 == 0 && wide3) { p.cfg = 3; p.bm = 256; p.bn = 128; resident_default = kSkResident / 2; }  // one workgroup per CU
+  else if (Cout % 128 == 0) { p.cfg = 0; p.bm = 128; p.bn = 128; }
   else if (Cout % 64 == 0) { p.cfg = 1; p.bm = 256; p.bn = 64; }
   else { p.cfg = 2; p.bm = 256; p.bn = 32; }
   const long total = ((M + p.bm - 1) / p.bm) * (Cout / p.bn) * ntaps * (Cin / BK);
   // one resident set of workgroups with equal ranges; small problems: at least 4 K-steps per workgroup
   static const long forced = [] { const char* e = getenv("SFM_ASPP_NWG"); return e ? atol(e) : 0L; }();  // experiments
-  const long resident = forced > 0 ? forced : kSkResident;
+  const long resident = forced > 0 ? forced : resident_default;
   p.nwg = total / 4 < resident ? (total / 4 > 0 ? total / 4 : 1) : resident;
   return p;
 }
@@ -900,23 +953,25 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
   if (ntaps == 1) rate = 0;
   const int K = ntaps * (Cin / BK);
   const long tiles = ((M + p.bm - 1) / p.bm) * (Cout / p.bn);
-#define SFM_CONV_LAUNCH(BM_, BN_, WM_, WN_)                                                                              \
+#define SFM_CONV_LAUNCH(BM_, BN_, WM_, WN_, ST_, NT_)                                                                    \
   do {                                                                                                                  \
     if (ep.scale)                                                                                                       \
-      hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, true>), dim3((unsigned)p.nwg), dim3(conv_threads(BM_, BN_, WM_, WN_)), 0, stream, in, wt, \
+      hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, true, ST_>), dim3((unsigned)p.nwg), dim3(NT_), 0, stream, in, wt, \
                          out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                              \
     else                                                                                                                \
-      hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false>), dim3((unsigned)p.nwg), dim3(conv_threads(BM_, BN_, WM_, WN_)), 0, stream, in,    \
+      hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false, ST_>), dim3((unsigned)p.nwg), dim3(NT_), 0, stream, in,    \
                          wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                          \
     hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, false, false>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
                        0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, 1, ep);                                     \
   } while (0)
-  if (p.cfg == 0)
-    SFM_CONV_LAUNCH(128, 128, 64, 64);
+  if (p.cfg == 3)
+    SFM_CONV_LAUNCH(256, 128, 64, 64, 3, 768);
+  else if (p.cfg == 0)
+    SFM_CONV_LAUNCH(128, 128, 64, 64, 2, 512);
   else if (p.cfg == 1)
-    SFM_CONV_LAUNCH(256, 64, 64, 64);
+    SFM_CONV_LAUNCH(256, 64, 64, 64, 2, 512);
   else
-    SFM_CONV_LAUNCH(256, 32, 64, 32);
+    SFM_CONV_LAUNCH(256, 32, 64, 32, 2, 512);
 #undef SFM_CONV_LAUNCH
   return sfm_last_error();
 }

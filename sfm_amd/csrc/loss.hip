@@ -182,8 +182,13 @@ __global__ __launch_bounds__(kBlock) void loss_tile_shift_kernel(const float* __
 // SOLO = the stand-alone operator (sfm_splat_warp_fwd: one image set, S = N = 1): no gather, `trans` may be null, and Acc
 // IS the zero-initialised side accumulator - the tile is flushed into it with float atomics (one add per element, no
 // contention) because overflow corners of other workgroups land in the same buffer.
+#ifdef SFM_SPLAT_WPE
+#define SFM_SPLAT_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SFM_SPLAT_WPE, SFM_SPLAT_WPE)))
+#else
+#define SFM_SPLAT_WPE_ATTR
+#endif
 template <bool PYR, bool SOLO = false>
-__global__ __launch_bounds__(kSplatThreads) void loss_splat_tile_kernel(const float* __restrict__ tgt,
+__global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_tile_kernel(const float* __restrict__ tgt,
                                                                  const float* __restrict__ src,
                                                                  const float* __restrict__ depth,
                                                                  const float* __restrict__ trans, PyrMaps pm,
