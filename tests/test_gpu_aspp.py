@@ -21,6 +21,12 @@ CASES = [  # (B, H, W, Cin, Cout, rate): every tile configuration, ragged M, rat
     (1, 16, 52, 64, 64, 6),     # 9-tap row-segment weight gradient, ragged last segment
     (2, 12, 40, 128, 32, 3),    # the same with two input-channel blocks
     (1, 9, 70, 64, 32, 16),     # its largest rate
+    # round 2 (stream-K ranges, loader waves, LDS-DMA): shapes that stress the loaders' coordinate tracking and the slabs
+    (1, 7, 9, 128, 128, 2),     # M = 63: one ragged tile, K-steps of the weight gradient end inside a 32-pixel step
+    (3, 11, 27, 128, 64, 2),    # M = 891: ragged against 128 / 256 rows, every range cuts a tile
+    (2, 40, 5, 32, 128, 1),     # W < 8: a DMA instruction's 8 rows wrap over image rows; Cin = 32 (one channel step per tap)
+    (1, 3, 3, 256, 256, 3),     # 9 pixels, rate = image size: only the centre tap is ever valid
+    (5, 6, 50, 160, 96, 5),     # five images in one tile range, odd channel multiples
 ]
 
 
