@@ -164,7 +164,11 @@ class _SyncBatchNormElu(torch.autograd.Function):
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.beta_ref = beta if beta.data_ptr() in _grad_sinks else None
         ctx.act, ctx.group = int(act), group
-        ctx.m_global = int(round(float(stats_all[:, 0, 0].sum())))
+        if stats_override is None:
+            from .loss import global_batch  # the rows of all ranks: exchanged once per (group, local count), then cached
+            ctx.m_global = global_batch(M, group, x.device)
+        else:
+            ctx.m_global = int(round(float(stats_all[:, 0, 0].sum())))
         ctx.rehearsed = stats_override is not None
         ctx.mark_non_differentiable(mean, invstd)
         return y, mean, invstd
