@@ -304,7 +304,7 @@ def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scal
     def step():
         p = eng.forward_partials(*a, ne, True)
         if world > 1:
-            dist.all_reduce(p)
+            allreduce_(p)
         return eng.backward(*a, p, ne, 1.0, True)
 
     def fence():
@@ -351,6 +351,21 @@ def slices_leg(dev) -> dict:
     return out
 
 
+def allreduce_(t, op=None):
+    """dist.all_reduce in place.  RCCL reduces the device tensor itself; the rehearsal backend (SFM_BENCH_BACKEND=gloo,
+    several ranks on one GPU) stages through host memory - gloo's own device path hangs with two ranks on one ROCm
+    device."""
+    import torch.distributed as dist
+    kw = {} if op is None else {"op": op}
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, **kw)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, **kw)
+    return t
+
+
 def strong_scaling_legs(dev, world, rank) -> dict:
     """configs[2] / configs[3]: the global batch fixed, B/world snippets per rank, one all-reduce per step."""
     import torch
@@ -376,7 +391,7 @@ def strong_scaling_legs(dev, world, rank) -> dict:
             err, dt, r = f"{type(e).__name__}: {e}", float("nan"), {}
         if world > 1:
             t = torch.tensor([dt if err is None else float("inf")], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            allreduce_(t, dist.ReduceOp.MAX)
             dt = float(t.item())
         if err is not None or dt == float("inf"):
             out[key] = {"workload": label, "error": err or "a rank failed"}
@@ -451,7 +466,7 @@ def rehearse(args) -> None:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_(t, dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps({"metric": "launcher rehearsal (no kernels)", "value": None, "unit": "Gpix/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "seconds": float(t.item())}), flush=True)
@@ -482,6 +497,9 @@ def main() -> None:
     if args.rehearse_launcher:
         return rehearse(args)
 
+    if os.environ.get("SFM_BENCH_WATCHDOG"):  # seconds: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SFM_BENCH_WATCHDOG"]), exit=True)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -489,6 +507,11 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    # rehearsal aid (one GPU, several ranks): SFM_BENCH_BACKEND=gloo takes RCCL out (it refuses two ranks on one device)
+    # and every rank uses cuda:(local_rank mod visible devices); the collectives then go through host memory
+    backend = os.environ.get("SFM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # rehearsal aid: SFM_BENCH_FORCE_DP=1 runs the N > 1 sequence (process group, hidden all-reduces) on one GPU
@@ -504,10 +527,12 @@ def main() -> None:
         try:
             if force_dp:
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            else:
+            elif backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
             warm = torch.zeros(8, dtype=torch.float64, device=dev)
-            dist.all_reduce(warm)
+            allreduce_(warm)
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
@@ -530,7 +555,7 @@ def main() -> None:
     def step_plain():
         partials = eng.forward_partials(tgt, src, K, depth, pose, trans, n_elem_global, True)
         if world > 1 or force_dp:
-            dist.all_reduce(partials)
+            allreduce_(partials)
         return eng.backward(tgt, src, K, depth, pose, trans, partials, n_elem_global, 1.0, True)
 
     def step():
@@ -556,7 +581,7 @@ def main() -> None:
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_(t, dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out[0])
 
