@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 H, W, B, S, N = 128, 416, 8, 4, 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-PREHEAT_STEPS = 30     # untimed, before the caller's --warmup: first touch of the workspace, clock ramp
+PREHEAT_STEPS = 200  # untimed, before the caller's warm-up: the clocks of an idle GPU ramp over the first ~100 steps (30 ms) - with 30 pre-heat steps a --steps 20 --warmup 5 run read 0.273 ms, with 200 it reads the steady 0.261 ms
 STAGES = ["tile_shift", "warp_fwd", "stencil", "reduce", "finalize", "warp_bwd", "pose_grad"]
 KERNEL_OF = {"warp_fwd": ["loss_splat_tile_kernel"], "stencil": ["loss_stencil_gather_kernel", "loss_stencil_splat_kernel"],
              "warp_bwd": ["loss_warp_bwd_kernel"]}
