@@ -711,28 +711,28 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
 // row dy = (w - 1) rate, 3 taps x 2 MFMA tiles each.  36 flop/byte at rate 3.
 // grid ((Cin / 64) * (Cout / 32), splits); a split covers row segments [z * sps, (z + 1) * sps).
 constexpr int kSegMaxRate = 16;
-__global__ __launch_bounds__(192, 2) void aspp_wgrad9_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+__global__ __launch_bounds__(384, 2) void aspp_wgrad9_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                           float* __restrict__ gw, int B, int H, int W, int Cin, int Cout,
                                                           int rate, long sps) {
-  constexpr int BM = 64, BN = 32, LDA = BM + 4, LDB = BN + 4, NT = 192;
+  constexpr int BM = 64, BN = 32, LDA = BM + 4, LDB = BN + 4, NT = 384;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int PW = BK + 2 * rate;              // patch width in pixels
   float* As = lds;                           // [3][PW][LDA]
   float* Bs = lds + 3 * PW * LDA;            // [BK][LDB]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  // six waves: wave = tap row + 3 * (half of the 64 input channels) - one 32x32 MFMA tile per tap and wave.  (Three
+  // waves with both halves each held 96 accumulator + 64 staging registers: two waves per SIMD, 6 waves over 4 SIMDs.)
+  const int tid = threadIdx.x, wave6 = tid >> 6, wave = wave6 % 3, half = wave6 / 3, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int ntn = Cout / BN;
   const int ci0 = (blockIdx.x / ntn) * BM, co0 = (blockIdx.x % ntn) * BN;
   const int nseg = (W + BK - 1) / BK;
   const long nsteps = (long)B * H * nseg;
   const long s0 = (long)blockIdx.y * sps, s1 = min(nsteps, s0 + sps);
 
-  f32x16 acc[3][2];
+  f32x16 acc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) acc[j][i][reg] = 0.f;
+    for (int reg = 0; reg < 16; ++reg) acc[j][reg] = 0.f;
 
   // staging: every thread owns up to kAIt float4 of the patch and kBIt of the gout tile; the next step's
   // global loads are issued into registers before the MFMAs of the current one
@@ -786,9 +786,8 @@ __global__ __launch_bounds__(192, 2) void aspp_wgrad9_kernel(const float* __rest
       const float b = Bs[(kk + h) * LDB + r];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float* ap = Aw + (kk + h + j * rate) * LDA + r;   // input pixel k + (j - 1) rate = patch pixel k + j rate
-        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[0], b, acc[j][0], 0, 0, 0);
-        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32], b, acc[j][1], 0, 0, 0);
+        const float* ap = Aw + (kk + h + j * rate) * LDA + 32 * half + r;   // input pixel k + (j - 1) rate = patch pixel k + j rate
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[0], b, acc[j], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -799,12 +798,10 @@ __global__ __launch_bounds__(192, 2) void aspp_wgrad9_kernel(const float* __rest
     float* ot = o + (long)(wave * 3 + j) * Cin * Cout;
     const int c = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int rr = ci0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        ot[(long)rr * Cout + co0 + c] = acc[j][i][reg];
-      }
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rr = ci0 + half * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      ot[(long)rr * Cout + co0 + c] = acc[j][reg];
+    }
   }
 }
 
@@ -912,7 +909,7 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cin, int Cout, int rate, in
   if (ntaps == 9 && Cin % 64 == 0 && (Cin % 128 != 0 || Cout % 64 != 0) && rate <= kSegMaxRate && W >= BK) {
     p.cfg = 4; p.bm = 64; p.bn = 32;
     const long nsteps = (long)B * H * ((W + BK - 1) / BK), base = (long)(Cin / 64) * (Cout / 32);
-    long splits = (768 + base - 1) / base;               // ~3 workgroups of 3 waves per CU
+    long splits = (512 + base - 1) / base;               // 2 workgroups of 6 waves per CU: one resident round (768: 240 us, 512: 225)
     if (splits > nsteps / 8) splits = nsteps / 8 > 0 ? nsteps / 8 : 1;
     p.pps = (nsteps + splits - 1) / splits;
     p.splits = (int)((nsteps + p.pps - 1) / p.pps);
@@ -1056,7 +1053,7 @@ static int launch_wgrad(const float* in, const float* gout, int B, int H, int W,
   const dim3 grid((Cin / p.bm) * (Cout / p.bn), ntaps, p.splits);
   if (p.cfg == 4) {
     const size_t lds = (size_t)(3 * (BK + 2 * rate) * 68 + BK * 36) * sizeof(float);
-    hipLaunchKernelGGL(aspp_wgrad9_kernel, dim3((Cin / 64) * (Cout / 32), p.splits), dim3(192), lds, stream, in, gout, dst, B, H,
+    hipLaunchKernelGGL(aspp_wgrad9_kernel, dim3((Cin / 64) * (Cout / 32), p.splits), dim3(384), lds, stream, in, gout, dst, B, H,
                        W, Cin, Cout, rate, p.pps);
   } else if (p.cfg == 0 || p.cfg == 1) {
     const long M = (long)B * H * W;
