@@ -17,6 +17,7 @@ taken before its clip (utils.py:573-575).  Gradients are per-sample: no collecti
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -238,6 +239,19 @@ def allreduce_partials(partials: Tensor, process_group=None) -> Tensor:
     return partials
 
 
+_SIDE_STREAM = os.environ.get("SFM_LOSS_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    """one extra stream per device for work that runs beside the fused step (the regulariser)"""
+    key = torch.device(device).index
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _FusedTotalLoss(torch.autograd.Function):
     """total_loss(pred_poses [B,N,6], pred_depth[0..S), pred_exp_logits[0..S), pred_disp[0..S) or nothing).
 
@@ -275,13 +289,29 @@ class _FusedTotalLoss(torch.autograd.Function):
                 # ONE fp64 buffer = ONE all-reduce: the S*(3N+1) partial sums, then this rank's share of the regulariser,
                 # written there by its kernel and added to the loss by the backward kernel (no torch arithmetic at all)
                 buf = torch.empty(eng.n_partials + (1 if smooth_weight > 0 else 0), dtype=torch.float64, device=tgt.device)
+            side = None
             if smooth_weight > 0:
                 ws_, wa_ = P.smooth_weights(S, smooth_weight, explain_reg_weight)
-                sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need,
-                                              out_f64=buf[eng.n_partials:] if buf is not None else None)
+                if fused_maps and _SIDE_STREAM and torch.cuda.is_current_stream_capturing():
+                    # the regulariser (value and gradient: ~40 us of small kernels at c2) on a second stream beside the
+                    # forward kernels; joined before the first reader of its outputs (the all-reduce / the backward).
+                    # Only while a HIP graph is being captured (GraphedTotalLoss: a parallel branch, 0.384 -> 0.374 ms per
+                    # replay); the eager sequence is bound by the host, which the fork and join cost 19 us more
+                    main = torch.cuda.current_stream(tgt.device)
+                    side = _side_stream(tgt.device)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need,
+                                                      out_f64=buf[eng.n_partials:])
+                else:
+                    sm, g_smooth = P.smooth_terms(pred_disp + pred_exp, ws_, wa_, global_b, need,
+                                                  out_f64=buf[eng.n_partials:] if buf is not None else None)
             try:
                 if fused_maps:
                     eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf)
+                    if side is not None:
+                        torch.cuda.current_stream(tgt.device).wait_stream(side)
+                        side = None
                     if global_b != B or process_group is not None:
                         allreduce_partials(buf, process_group)
                     d_into = g_smooth[S:] if g_smooth is not None else None
@@ -307,6 +337,8 @@ class _FusedTotalLoss(torch.autograd.Function):
             except Exception:
                 # a failure between the two halves (rejected argument, failed collective) can leave the splat's overflow
                 # accumulator and flags raised: restore the invariant and do not reuse this workspace
+                if side is not None:
+                    torch.cuda.current_stream(tgt.device).wait_stream(side)
                 eng.reinit()
                 _evict_engine(eng)
                 raise
