@@ -338,3 +338,27 @@ def test_grad_buckets_receive_the_weight_gradients_in_place(dev):
         t.grad = None
     loss().backward()
     assert w3.grad.data_ptr() != gb.grad(w3).data_ptr()                        # released: ordinary tensors again
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,rate", [(2, 8, 26, 256, 128, 2), (1, 16, 52, 128, 64, 3), (1, 12, 40, 64, 32, 3)])
+def test_convolutions_are_bitwise_reproducible(dev, B, H, W, Cin, Cout, rate):
+    """stream-K slabs are added in workgroup order and the weight-gradient fix-up in a fixed group order: no atomics, so two
+    runs of the same call give the same bits (forward, backward data, backward weight, 3x3 and 1x1)"""
+    g = torch.Generator().manual_seed(401)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w3 = (torch.randn(3, 3, Cin, Cout, generator=g) / (3.0 * Cin ** 0.5)).to(dev)
+    w1 = (torch.randn(1, 1, Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
+    go = torch.randn(B, H, W, Cout, generator=g).to(dev)
+
+    def run():
+        xs, a, b = x.clone().requires_grad_(True), w3.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+        y3, y1 = sfm_amd.dilated_conv3x3(xs, a, rate), sfm_amd.conv1x1(xs, b)
+        (y3 * go).sum().backward(retain_graph=True)
+        g3 = (xs.grad.clone(), a.grad.clone())
+        xs.grad = None
+        (y1 * go).sum().backward()
+        return y3.detach(), y1.detach(), g3[0], g3[1], xs.grad, b.grad
+
+    first, second = run(), run()
+    for u, v in zip(first, second):
+        assert torch.equal(u, v)

@@ -92,3 +92,26 @@ def test_sync_batch_norm_over_a_one_rank_rccl_group_equals_plain_batch_norm(dev,
         outs.append((y.detach(), xr.grad, gr.grad, br.grad, mm, mv))
     for a, b in zip(*outs):
         assert (a - b).abs().max() <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_decoder_level_with_synchronised_batch_norm_on_a_one_rank_group(dev, nccl_world1):
+    """disp_bottleneck_dense(process_group=...): every batch norm of the block on the gathered statistics; with one rank
+    that is the plain block up to the order of the fp64 merges"""
+    import torch.distributed as dist
+    g = torch.Generator().manual_seed(77)
+    cin, cout, B, h, w = 64, 32, 2, 6, 10
+    def conv(k, ci, co):
+        return dict(w=(torch.randn(k, k, ci, co, generator=g) / (k * ci ** 0.5)).to(dev), gamma=(torch.rand(co, generator=g) + 0.5).to(dev),
+                    beta=(torch.randn(co, generator=g) * 0.1).to(dev))
+    p = dict(up=conv(1, cin, cin), sup=conv(1, cin, cout), aspp_up=conv(3, cin, cout), aspp_up2=conv(3, 2 * cout, cout),
+             out=conv(1, 4 * cout, cout), skip=conv(3, 2 * cout, cout))
+    concat = torch.randn(B, h, w, cin, generator=g).to(dev)
+    wy = torch.randn(B, 2 * h, 2 * w, cout, generator=g).to(dev)
+    res = []
+    for pg in (None, dist.group.WORLD):
+        c = concat.clone().requires_grad_(True)
+        y, u = sfm_amd.disp_bottleneck_dense(p, c, None, (3, 6), False, False, None, process_group=pg)
+        (y * wy).sum().backward()
+        res.append((y.detach(), u.detach(), c.grad))
+    for a, b in zip(*res):
+        assert rel_err(a, b) <= 2e-5
