@@ -51,7 +51,7 @@ __device__ __forceinline__ void mma_step(const float* __restrict__ As, const flo
 }
 
 // Optional per-output-channel epilogue of the forward convolution, applied where the finished sum is stored (the MFMA
-// kernel's store loop, or the slab reduction when the taps are split): y = act(x * scale[c] + shift[c]) - batch norm in
+// kernel's store loop, or the stream-K fix-up when several ranges cut the tile): y = act(x * scale[c] + shift[c]) - batch norm in
 // INFERENCE mode folded to one FMA (scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean * scale) and ELU.
 // scale == nullptr: none.  (Training-mode batch norm needs the statistics of the whole output first: csrc/bn_elu.hip.)
 struct Epilogue {

@@ -16,7 +16,7 @@ CASES = [  # (B, H, W, Cin, Cout, rate): every tile configuration, ragged M, rat
     (1, 5, 7, 32, 32, 1),
     (2, 9, 13, 64, 32, 2),      # last-level shape class (64 -> 32), split weight gradient
     (1, 8, 26, 128, 64, 3),     # 128 -> 64
-    (2, 8, 26, 256, 128, 4),    # 128-wide tiles, tap-split forward
+    (2, 8, 26, 256, 128, 4),    # 128-wide tiles, few tiles: every stream-K range cuts one
     (1, 6, 6, 96, 160, 12),     # odd multiples of 32, rate larger than the image
     (1, 16, 52, 64, 64, 6),     # 9-tap row-segment weight gradient, ragged last segment
     (2, 12, 40, 128, 32, 3),    # the same with two input-channel blocks
@@ -285,7 +285,7 @@ def test_disp_bottleneck_dense_block(dev, cin, cout, rates, use_skip, use_skip2)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,rate,act", [
-    (2, 8, 26, 256, 128, 2, True),     # small M: taps split over workgroups, epilogue in the slab reduction
+    (2, 8, 26, 256, 128, 2, True),     # small M: tiles cut by several stream-K ranges, epilogue in the fix-up kernel
     (2, 32, 52, 64, 32, 3, True),      # 256x32 tiles, epilogue in the MFMA kernel's store loop
     (1, 16, 40, 128, 64, 6, False),    # batch norm alone (activation_fn=None)
 ])
