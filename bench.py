@@ -3,8 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the fused hot path (sfm_pose_setup -> sfm_loss_forward -> [all-reduce of the fp64
-partial sums when N > 1] -> sfm_loss_backward) over one batch of synthetic KITTI-shaped snippets that is
+One step = one pass of the fused hot path (sfm_pose_setup -> sfm_loss_forward -> sfm_loss_backward; when N > 1 the
+forward is made in three calls with the all-reduce of the S*N fp64 mask sums beside the gather-side stencil, and the
+S*(3N+1) fp64 partial sums are all-reduced before the backward) over one batch of synthetic KITTI-shaped snippets that is
 already resident in HBM.  Workload (configs[1] of BASELINE.json): 416x128, B=8 per GPU, seq=3 (2 sources),
 4 scales.  Weak scaling: every rank holds its own 8 snippets; the loss is the global one.
 
@@ -45,7 +46,7 @@ sys.path.insert(0, ROOT)
 H, W, B, S, N = 128, 416, 8, 4, 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 PREHEAT_STEPS = 200  # untimed, before the caller's warm-up: the clocks of an idle GPU ramp over the first ~100 steps (30 ms) - with 30 pre-heat steps a --steps 20 --warmup 5 run read 0.273 ms, with 200 it reads the steady 0.261 ms
-STAGES = ["tile_shift", "warp_fwd", "stencil", "reduce", "finalize", "warp_bwd", "pose_grad"]
+STAGES = ["tile_shift", "warp_fwd", "stencil", "reduce", "seed_guard", "warp_bwd", "pose_grad", "mask_sums"]
 KERNEL_OF = {"warp_fwd": ["loss_splat_tile_kernel"], "stencil": ["loss_stencil_gather_kernel", "loss_stencil_splat_kernel"],
              "warp_bwd": ["loss_warp_bwd_kernel"]}
 STEP_BYTES_PER_PAIR = 108 + 152  # gather direction 108 B + splat direction 152 B per (pixel, scale, source)
@@ -61,8 +62,8 @@ def algorithmic_bytes(n_src: int) -> dict:
     n, g = n_src, min(n_src, 2)
     return {
         "warp_fwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 16 * n,   # depth, tgt, trans, src taps; G out, Acc out
-        "stencil": 16 * n + 12 * n + 12 * g + 12 + 32 * n + 12 * g,   # Acc, src, G, tgt in; Hb (2 parts), dG out
-        "warp_bwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 32 * n + 4 + 12 * n,  # + dG, Hb in; d_depth, d_trans out
+        "stencil": 16 * n + 12 * n + 12 * g + 12 + 16 * n + 12 * g,   # Acc, src, G, tgt in; Hb, dG out
+        "warp_bwd": 4 + 12 + 12 * n + 12 * g + 12 * g + 16 * n + 4 + 12 * n,  # + dG, Hb in; d_depth, d_trans out
     }
 
 
@@ -288,6 +289,10 @@ def leg_bytes_gib(b, h, w, s, n) -> float:
     return (ws + io) * 4 / 2 ** 30
 
 
+class LegSetupError(RuntimeError):
+    """a leg could not be set up (allocation) on some rank; every rank knows and skips the leg"""
+
+
 def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scale=0.01, with_flags=False) -> dict:
     """The fused step on `b` snippets of this rank (inputs generated on the device); under world > 1 with the
     stream-ordered all-reduce of the partial sums and the global denominators.  Returns this rank's timing (the caller
@@ -296,13 +301,26 @@ def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scal
     import torch.distributed as dist
     from sfm_amd import synth
     from sfm_amd.loss import LossEngine
-    inp = synth.make_step_inputs_device(b, h, w, s, n, synth.SEED + 101 * rank, dev, pose_scale=pose_scale, cityscapes=city)
-    eng = LossEngine(b, h, w, s, n, dev)
+    # allocation under try on every rank, then ONE agreement before the first collective of the leg: a rank that could
+    # not allocate must not leave the others waiting in the step's all-reduces
+    err = None
+    try:
+        inp = synth.make_step_inputs_device(b, h, w, s, n, synth.SEED + 101 * rank, dev, pose_scale=pose_scale, cityscapes=city)
+        eng = LossEngine(b, h, w, s, n, dev)
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if world > 1:
+        ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+        allreduce_(ok, dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            raise LegSetupError(err or "another rank could not allocate this leg")
+    elif err:
+        raise LegSetupError(err)
     ne = world * b * h * w * 3
     a = (inp["tgt"], inp["src"], inp["K"], inp["depth"], inp["pose"], inp["trans"])
 
     def step():
-        p = eng.forward_partials(*a, ne, True)
+        p = eng.forward_partials(*a, ne, True, msum_allreduce=MSUM_ALLREDUCE)
         if world > 1:
             allreduce_(p)
         return eng.backward(*a, p, ne, 1.0, True)
@@ -351,6 +369,9 @@ def slices_leg(dev) -> dict:
     return out
 
 
+MSUM_ALLREDUCE = None  # set in main() for the rehearsal backend: the mask sums staged through host memory as well
+
+
 def allreduce_(t, op=None):
     """dist.all_reduce in place.  RCCL reduces the device tensor itself; the rehearsal backend (SFM_BENCH_BACKEND=gloo,
     several ranks on one GPU) stages through host memory - gloo's own device path hangs with two ranks on one ROCm
@@ -364,6 +385,12 @@ def allreduce_(t, op=None):
     else:
         dist.all_reduce(t, **kw)
     return t
+
+
+def collective_backend() -> str:
+    import torch.distributed as dist
+    b = dist.get_backend() if dist.is_initialized() else "none"
+    return "RCCL" if b == "nccl" else f"{b} (rehearsal: staged through host memory)"
 
 
 def strong_scaling_legs(dev, world, rank) -> dict:
@@ -383,25 +410,27 @@ def strong_scaling_legs(dev, world, rank) -> dict:
                                                       f"{MEM_BUDGET_GIB:.0f} GiB budget of one 288 GB GPU)"}
             continue
         steps, warm = (10, 3) if key == "c3" else (4, 2)
-        err = None
         try:
             r = fused_step_leg(dev, b, c["H"], c["W"], c["S"], c["N"], c["city"], world, rank, steps, warm)
-            dt = r["dt"]
-        except Exception as e:
-            err, dt, r = f"{type(e).__name__}: {e}", float("nan"), {}
+        except LegSetupError as e:  # agreed on by every rank before the leg's first collective
+            out[key] = {"workload": label, "error": str(e)}
+            continue
+        except Exception:
+            if world > 1:
+                raise  # inside the timed loop the ranks' collectives no longer pair: exit non-zero, do not go on
+            raise
+        dt = r["dt"]
         if world > 1:
-            t = torch.tensor([dt if err is None else float("inf")], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
             allreduce_(t, dist.ReduceOp.MAX)
             dt = float(t.item())
-        if err is not None or dt == float("inf"):
-            out[key] = {"workload": label, "error": err or "a rank failed"}
-            continue
         units = c["B"] * c["H"] * c["W"] * c["S"] * c["N"] * 2
         out[key] = {"workload": label, "scaling": "strong", "n_gpus": world, "per_gpu_batch": b, "ms_per_step": dt * 1e3,
                     "Gpix_per_s": units / dt / 1e9,
                     "step_frac_of_hbm_peak_per_gpu": STEP_BYTES_PER_PAIR / 2 * units / world / dt / 1e9 / HBM_PEAK_GBS,
-                    "collectives": "none" if world == 1 else f"1 RCCL all-reduce(sum) of {c['S'] * (3 * c['N'] + 1)} fp64 partial "
-                                                             f"sums per step, stream-ordered between the two halves",
+                    "collectives": "none" if world == 1 else
+                    f"{collective_backend()} all-reduce(sum) of {c['S'] * c['N']} fp64 mask sums beside the gather-side stencil + "
+                    f"all-reduce(sum) of {c['S'] * (3 * c['N'] + 1)} fp64 partial sums, stream-ordered before the backward",
                     "workspace_GiB_per_gpu": r.get("workspace_GiB"), "loss": r.get("loss")}
     return out
 
@@ -485,11 +514,6 @@ def main() -> None:
     ap.add_argument("--no-strong", action="store_true", help="skip the configs[2] / configs[3] strong-scaling legs")
     ap.add_argument("--rehearse-launcher", action="store_true", help="CPU rehearsal of the launcher and rank plumbing "
                     "(gloo, no kernels)")
-    ap.add_argument("--overlap-allreduce", action="store_true",
-                    help="N > 1: two all-reduces hidden under kernels (LossEngine.step_dp) instead of the one "
-                         "stream-ordered all-reduce between the two halves; costs ~46 us of extra launches and "
-                         "stream hand-offs per step (measured with a 1-rank group), so it only pays when the "
-                         "collective itself is slower than that")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -497,9 +521,13 @@ def main() -> None:
     if args.rehearse_launcher:
         return rehearse(args)
 
-    if os.environ.get("SFM_BENCH_WATCHDOG"):  # seconds: dump every thread's stack and exit if the run takes longer
+    # Watchdog: dump every thread's stack and exit non-zero if the run takes longer than this many seconds.  On by default
+    # for N > 1 (540 s, below the driver's 600 s limit: a stalled RCCL bring-up then leaves stacks instead of a bare
+    # time-out); SFM_BENCH_WATCHDOG=<s> sets it, 0 turns it off.
+    wd = os.environ.get("SFM_BENCH_WATCHDOG", "540" if args.gpus > 1 else "0")
+    if wd.isdigit() and int(wd) > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["SFM_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(int(wd), exit=True)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -550,18 +578,19 @@ def main() -> None:
     eng = LossEngine(B, H, W, S, N, dev)
     n_elem_global = world * B * H * W * 3
 
-    overlapped = (world > 1 or force_dp) and args.overlap_allreduce
+    global MSUM_ALLREDUCE
+    if (world > 1 or force_dp) and backend != "nccl":
+        MSUM_ALLREDUCE = lambda t: allreduce_(t) and None  # noqa: E731  (synchronous, through host memory)
+    dp = world > 1 or force_dp
 
-    def step_plain():
-        partials = eng.forward_partials(tgt, src, K, depth, pose, trans, n_elem_global, True)
-        if world > 1 or force_dp:
+    def step():
+        partials = eng.forward_partials(tgt, src, K, depth, pose, trans, n_elem_global, True, dp=dp,
+                                        msum_allreduce=MSUM_ALLREDUCE)
+        if dp:
             allreduce_(partials)
         return eng.backward(tgt, src, K, depth, pose, trans, partials, n_elem_global, 1.0, True)
 
-    def step():
-        if overlapped:  # both all-reduces hidden under kernels (LossEngine.step_dp)
-            return eng.step_dp(tgt, src, K, depth, pose, trans, n_elem_global)[:4]
-        return step_plain()
+    step_plain = step
 
     def fence():
         if world > 1:
@@ -608,7 +637,7 @@ def main() -> None:
         dom = max(ab, key=lambda n: per_stage_us[n])
         launch_bytes = ab[dom] * B * H * W * S
         achieved = launch_bytes / (per_stage_us[dom] * 1e-6) / 1e9
-        traffic = None
+        traffic = None  # a committed constant of this workload (rocprofv3 PMC passes, tools/traffic.sh), not measured in this run
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from the TCC counters (tools/traffic.sh), same workload
             tj = json.load(open(tpath))
@@ -624,12 +653,15 @@ def main() -> None:
             "config": {"workload": f"{W}x{H} B={B}/GPU seq=3 (N={N} sources) S={S} scales, warp+photometric loss "
                                    f"fwd+bwd (BASELINE.json configs[1])",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "collectives": ("none" if world == 1 else ("2 all-reduces hidden under kernels" if overlapped
-                                                                   else "1 stream-ordered all-reduce of S*(3N+1) fp64 sums")),
+                       "collectives": ("none" if world == 1 else
+                                       f"{collective_backend()}: all-reduce of S*N fp64 mask sums beside the gather-side stencil + "
+                                       f"stream-ordered all-reduce of S*(3N+1) fp64 sums before the backward"),
                        "pixel_warps_per_step": units_per_gpu * world, "preheat_steps": PREHEAT_STEPS,
                        "loss": loss},
             "roofline": {"bound": "hbm", "kernel": "+".join(KERNEL_OF[dom]), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 PMC passes of this workload: "
+                                           "2*FETCH_SIZE + WRITE_SIZE per launch; a constant, not measured in this run)",
                          "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": per_stage_us[dom],
                          "stage_us": per_stage_us,
                          "step_algorithmic_bytes": step_bytes, "step_achieved": step_gbs,

@@ -144,36 +144,42 @@ int sfm_ssim_bwd(const float* img1, const float* img2, const float* gv, int B, i
  *
  * sfm_loss_forward writes partials[S*(3N+1)] (fp64): per scale, per source the sums
  * (sum m|Sp-src|, sum m, sum ssim(Sp,src)) and then sum min(e_0,e_1).  Under data
- * parallelism these are all-reduced (sum) across ranks before sfm_loss_backward; that is
- * the only collective of the path.
+ * parallelism these are all-reduced (sum) across ranks before sfm_loss_backward.
  * sfm_loss_backward turns the (global) sums into the loss (one float at loss_out; the
  * pixel_loss of :149+:168) and, if need_grad, into d_depth [S,B,H,W], d_trans [S,B,H,W,3N]
- * and d_pose [B,N,6], each scaled by gloss (dL/d loss).  n_elem_global = B_global*H*W*3. */
+ * and d_pose [B,N,6], each scaled by gloss (dL/d loss).  n_elem_global = B_global*H*W*3.
+ *
+ * sfm_loss_forward is the SINGLE-DEVICE forward: the backward seeds of the SSIM term carry the factor
+ * mean(proj_src_mask) of :144, 149, i.e. the global mask sums M(s, i) = sum m (utils.py:478-479), which
+ * it takes from this device's images alone.  A data-parallel step makes the forward in three calls instead
+ * (no counterpart in the single-device reference; same kernels, same arithmetic):
+ *   sfm_loss_forward_warps   both warps + this rank's mask sums msum[S*N] (fp64)
+ *   [all-reduce (sum) of msum over the ranks - on the communication stream, beside:]
+ *   sfm_loss_forward_gather  the gather-side stencil (min-reprojection term)
+ *   sfm_loss_forward_splat   the splat-side stencil with the GLOBAL mask sums, then partials[S*(3N+1)]
+ *   [all-reduce (sum) of partials]  ->  sfm_loss_backward
+ * (_gather before _splat; all on one stream or ordered by events.) */
 long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N);
 int sfm_loss_num_partials(int B, int H, int W, int S, int N);
 int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, int N, void* stream);
 int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
                      const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
                      int need_grad, double* partials, void* stream);
-/* The forward in two halves, so that a data-parallel step can hide its collectives (no counterpart in the
- * single-device reference; same arithmetic as sfm_loss_forward): _splat = both warps + the splat-side stencil and
- * its 3N sums per scale (written into the [S][3N+1] partials layout, the min-reprojection slots untouched);
- * _gather = the gather-side stencil and the min-reprojection sums e_sums[S] (fp64).  Order per step:
- * _splat, [all-reduce partials] || _gather, [all-reduce e_sums] || sfm_loss_backward (its loss_out is then
- * meaningless), sfm_loss_value(partials, e_sums) for the loss. */
-int sfm_loss_forward_splat(const float* tgt, const float* src, const float* depth, const float* trans,
-                           const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
-                           int need_grad, double* partials, void* stream);
-int sfm_loss_forward_gather(const float* tgt, const float* src, const float* depth, const float* trans,
-                            const float* params, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
-                            int need_grad, double* partials, double* e_sums, void* stream);
-int sfm_loss_value(const double* partials, const double* e_sums, int S, int N, long long n_elem_global, float* loss_out,
-                   void* stream);
+int sfm_loss_forward_warps(const float* tgt, const float* src, const float* depth, const float* trans,
+                           const float* params, float* ws, int B, int H, int W, int S, int N, double* msum, void* stream);
+int sfm_loss_forward_gather(const float* tgt, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
+                            int need_grad, void* stream);
+int sfm_loss_forward_splat(const float* src, float* ws, int B, int H, int W, int S, int N, long long n_elem_global,
+                           int need_grad, const double* msum_global, double* partials, void* stream);
 int sfm_loss_backward(const float* tgt, const float* src, const float* depth, const float* trans,
                       const float* params, float* ws, int B, int H, int W, int S, int N,
                       long long n_elem_global, float gloss, int need_grad, const double* partials,
                       const float* pose, const float* K, float* loss_out, float* d_depth, float* d_trans,
                       float* d_pose, void* stream);
+/* Test / debug aid (no counterpart in the reference): where region `which` of the workspace lies, in floats from ws -
+ * 0 Acc, 1 Ovf (the splat's overflow side accumulator), 2 Hb, 3 the per-tile overflow counters (int32), 4 the mask
+ * sums (fp64). */
+int sfm_loss_workspace_region(int B, int H, int W, int S, int N, int which, long long* offset, long long* count);
 
 /* The same step fed with the prediction PYRAMID instead of maps already resized to HxW: depth_s[s]
  * [B,h[s],w[s]] = pred_depth[s], trans_s[s] [B,h[s],w[s],3N] = pred_exp_logits[s] at their native sizes (HOST arrays of S
@@ -181,7 +187,8 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
  * tf.image.resize_bilinear(..., [H, W]) of SfMLearner_uni.py:91, 113 per pixel while loading (TF-1 defaults, the
  * arithmetic of sfm_pyramid_upsample_fwd bit for bit; a level at full size is read directly), so the [S,B,H,W,1+3N]
  * intermediate of sfm_pyramid_upsample_fwd is never written or read.  Everything else - workspace, partials, the
- * all-reduce between the two calls, loss_out, d_pose - as sfm_loss_forward / sfm_loss_backward.
+ * all-reduce between the two calls, loss_out, d_pose - as sfm_loss_forward / sfm_loss_backward; sfm_loss_forward_warps_pyr
+ * is sfm_loss_forward_warps fed this way (the other two calls of the data-parallel forward read no prediction map).
  * Backward: the adjoint of the resize runs inside the kernel too.  d_depth_s[s] [B,h[s],w[s]] and d_trans_s[s]
  * [B,h[s],w[s],3N] (host arrays of device pointers) receive the gradients of the pyramid's own maps, ADDED to their
  * contents: zero-fill them first, or pass maps that already hold another term of the gradient (the regulariser's,
@@ -193,6 +200,9 @@ int sfm_loss_backward(const float* tgt, const float* src, const float* depth, co
 int sfm_loss_forward_pyr(const float* tgt, const float* src, const float* const* depth_s, const float* const* trans_s,
                          const int* h, const int* w, const float* params, float* ws, int B, int H, int W, int S, int N,
                          long long n_elem_global, int need_grad, double* partials, void* stream);
+int sfm_loss_forward_warps_pyr(const float* tgt, const float* src, const float* const* depth_s,
+                               const float* const* trans_s, const int* h, const int* w, const float* params, float* ws, int B,
+                               int H, int W, int S, int N, double* msum, void* stream);
 int sfm_loss_backward_pyr(const float* tgt, const float* src, const float* const* depth_s, const float* const* trans_s,
                           const int* h, const int* w, const float* params, float* ws, int B, int H, int W, int S, int N,
                           long long n_elem_global, float gloss, int need_grad, const double* partials, int n_extra,
@@ -339,8 +349,8 @@ int sfm_snippet_unpack(const unsigned char* seq, const float* K, int B, int H, i
 /* ---- measurement aid (no counterpart in the reference; used by bench.py only) -----------
  * When enabled, sfm_loss_forward / sfm_loss_backward bracket each of their launches with
  * HIP events on the caller's stream; sfm_prof_read adds the last step's elapsed ms per stage
- * into ms[sfm_prof_stages()] (order: tile_shift, warp_fwd, stencil, reduce, finalize,
- * warp_bwd, pose_grad) after the caller synchronised.  Process-wide, off by default. */
+ * into ms[sfm_prof_stages()] (order: tile_shift, warp_fwd, stencil, reduce, finalize / seed guard,
+ * warp_bwd, pose_grad, mask sums) after the caller synchronised.  Process-wide, off by default. */
 int sfm_prof_enable(int on);
 int sfm_prof_stages(void);
 int sfm_prof_read(float* ms);

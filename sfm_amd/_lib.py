@@ -50,9 +50,11 @@ SIGNATURES = {
     "sfm_loss_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
     "sfm_loss_forward_pyr": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
     "sfm_loss_backward_pyr": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _F, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
-    "sfm_loss_forward_splat": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
-    "sfm_loss_forward_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P, _P],
-    "sfm_loss_value": [_P, _P, _I, _I, _LL, _P, _P],
+    "sfm_loss_forward_warps": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "sfm_loss_forward_warps_pyr": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "sfm_loss_forward_gather": [_P, _P, _I, _I, _I, _I, _I, _LL, _I, _P],
+    "sfm_loss_forward_splat": [_P, _P, _I, _I, _I, _I, _I, _LL, _I, _P, _P, _P],
+    "sfm_loss_workspace_region": [_I, _I, _I, _I, _I, _I, _P, _P],
     "sfm_aspp_conv3x3_workspace_floats": [_I, _I, _I, _I, _I],
     "sfm_aspp_conv3x3_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv3x3_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],

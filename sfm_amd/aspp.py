@@ -10,6 +10,8 @@ resnet/resnet_utils.py:232-251; csrc/bn_elu.hip), and ``conv2d_bn_elu`` chains t
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -18,18 +20,39 @@ from .utils import _check, _same_device
 
 Tensor = torch.Tensor
 _workspaces = {}
-_grad_sinks = {}  # data_ptr of a registered parameter -> (GradBuckets, bucket index, offset, shape)
+_grad_sinks = {}  # id of a registered parameter -> (weakref to it, GradBuckets, bucket index, offset, shape)
+
+
+def _sink_of(param):
+    """the GradBuckets slot of this very tensor object (an id that outlived its tensor and was reused matches nothing)"""
+    if param is None:
+        return None
+    slot = _grad_sinks.get(id(param))
+    if slot is None:
+        return None
+    if slot[0]() is not param:
+        del _grad_sinks[id(param)]
+        return None
+    return slot
 
 
 def _grad_out(param: Tensor) -> Tensor:
-    """Where a weight-gradient kernel writes: a fresh view into the parameter's slot of a ``GradBuckets`` if it is
-    registered in one (the gradient is then born inside the flat all-reduce buffer), else a new tensor."""
-    slot = _grad_sinks.get(param.data_ptr())
+    """Where a weight-gradient kernel writes: a view into the parameter's slot of a ``GradBuckets`` if it is registered
+    in one (the gradient is then born inside the flat all-reduce buffer), else a new tensor.  The slot is handed out
+    once per step: a second gradient of the same parameter before the next ``allreduce()`` (a weight used twice in one
+    graph, or gradient accumulation over several backward passes) gets a new tensor, which autograd ADDS to the
+    first - kernels overwrite their output, so writing the slot again would lose what it holds (and with ``.grad``
+    aliasing the slot, ``grad += slot`` would double the new gradient instead of accumulating)."""
+    slot = _sink_of(param)
     if slot is None:
         return torch.empty_like(param)
-    buckets, k, off, shape = slot
-    buckets._written[k] = True
-    return buckets.flat[k][off:off + param.numel()].view(shape)
+    _, buckets, k, off, shape = slot
+    view = buckets.flat[k][off:off + param.numel()].view(shape)
+    if (k, off) in buckets._written or (param.grad is not None and param.grad.data_ptr() == view.data_ptr()):
+        buckets._written.add((k, off))  # (an aliased .grad from an earlier step: what autograd adds lands in the slot)
+        return torch.empty_like(param)
+    buckets._written.add((k, off))
+    return view
 
 
 def _workspace(B, H, W, Cin, Cout, device) -> Tensor:
@@ -111,7 +134,7 @@ class _BatchNormElu(torch.autograd.Function):
             call("sfm_bn_elu_fwd", ptr(x), ptr(gamma), ptr(beta), M, C, float(epsilon), float(decay), int(act), ptr(moving_mean),
                  ptr(moving_var), ptr(y), ptr(mean), ptr(invstd), ptr(ws), stream_of(x))
         ctx.save_for_backward(x, y, gamma, mean, invstd)
-        ctx.beta_ref = beta if beta.data_ptr() in _grad_sinks else None  # only to find its slot in a GradBuckets
+        ctx.beta_ref = beta if _sink_of(beta) is not None else None  # only to find its slot in a GradBuckets
         ctx.act = int(act)
         ctx.mark_non_differentiable(mean, invstd)
         return y, mean, invstd
@@ -137,7 +160,7 @@ class _SyncBatchNormElu(torch.autograd.Function):
     forward, all-reduce of (sum dz xhat, sum dz) in the backward - two small collectives per layer and direction."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, decay, epsilon, act, group, stats_override):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, decay, epsilon, act, group, stats_override, global_rows):
         import torch.distributed as dist
         C = x.shape[-1]
         M = x.numel() // C
@@ -162,13 +185,11 @@ class _SyncBatchNormElu(torch.autograd.Function):
             call("sfm_bn_elu_apply_stats", ptr(x), ptr(gamma), ptr(beta), ptr(stats_all), world, M, C, float(epsilon),
                  float(decay), int(act), ptr(moving_mean), ptr(moving_var), ptr(y), ptr(mean), ptr(invstd), stream_of(x))
         ctx.save_for_backward(x, y, gamma, mean, invstd)
-        ctx.beta_ref = beta if beta.data_ptr() in _grad_sinks else None
+        ctx.beta_ref = beta if _sink_of(beta) is not None else None
         ctx.act, ctx.group = int(act), group
-        if stats_override is None:
-            from .loss import global_batch  # the rows of all ranks: exchanged once per (group, local count), then cached
-            ctx.m_global = global_batch(M, group, x.device)
-        else:
-            ctx.m_global = int(round(float(stats_all[:, 0, 0].sum())))
+        # rows of all ranks: given by the caller, else read from the gathered triples (every rank holds the same ones;
+        # no further collective, but one host synchronisation per call)
+        ctx.m_global = int(global_rows) if global_rows is not None else int(round(float(stats_all[:, 0, 0].sum())))
         ctx.rehearsed = stats_override is not None
         ctx.mark_non_differentiable(mean, invstd)
         return y, mean, invstd
@@ -196,20 +217,22 @@ class _SyncBatchNormElu(torch.autograd.Function):
                 dist.all_reduce(both, group=ctx.group)
             call("sfm_bn_elu_bwd_apply", ptr(x), ptr(y), ptr(gy), ptr(gamma), ptr(mean), ptr(invstd), ptr(both[0]), ptr(both[1]),
                  M, ctx.m_global, C, ctx.act, ptr(gx), stream_of(x))
-        return gx, ggamma, gbeta, None, None, None, None, None, None, None
+        return gx, ggamma, gbeta, None, None, None, None, None, None, None, None
 
     rehearsal_sums = None  # tests: callable mapping this "rank"'s [2, C] sums to the sums over the rehearsed world
 
 
 def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor = None, moving_var: Tensor = None,
                    decay: float = BN_DECAY, epsilon: float = BN_EPSILON, activation: bool = True,
-                   process_group=None, _stats_all: Tensor = None) -> Tensor:
+                   process_group=None, _stats_all: Tensor = None, global_rows: int = None) -> Tensor:
     """``tf.nn.elu(slim.batch_norm(x, decay, epsilon, scale=True, fused=True, is_training=True,
     updates_collections=None))`` - the normaliser + activation of the ASPP arg-scope (nets.py:653-656).
     x [..., C] NHWC; gamma, beta [C]; moving_mean / moving_var [C] are updated in place when given.
     ``activation=False``: the batch norm alone (``slim.conv2d(..., activation_fn=None)``, nets.py:455, 470).
     ``process_group``: statistics over the batches of ALL ranks of the group (synchronised batch norm: the
-    single-device graph on the global batch); default ``None`` = this rank's batch only."""
+    single-device graph on the global batch); default ``None`` = this rank's batch only.  ``global_rows``: the number
+    of rows (B*H*W) over all ranks when the caller knows it (fixed shards: world * rows); omitted, it is read from the
+    gathered statistics at the price of one host synchronisation per call."""
     x = _check(x, "x", x.dim() if isinstance(x, torch.Tensor) else 4)
     C = x.shape[-1]
     gamma = _check(gamma, "gamma", 1, C)
@@ -222,7 +245,7 @@ def batch_norm_elu(x: Tensor, gamma: Tensor, beta: Tensor, moving_mean: Tensor =
     _same_device(x, gamma, beta, moving_mean, moving_var)
     if process_group is not None or _stats_all is not None:
         return _SyncBatchNormElu.apply(x, gamma, beta, moving_mean, moving_var, float(decay), float(epsilon), bool(activation),
-                                       process_group, _stats_all)[0]
+                                       process_group, _stats_all, global_rows)[0]
     return _BatchNormElu.apply(x, gamma, beta, moving_mean, moving_var, float(decay), float(epsilon), bool(activation))[0]
 
 
@@ -347,8 +370,12 @@ class GradBuckets:
     ``params``: the weights / gammas / betas in the order the backward produces their gradients (last layer first).
     Registered parameters get their gradient from ``dilated_conv3x3`` / ``conv1x1`` / ``batch_norm_elu`` as a view
     into one of a few >= ``bucket_bytes`` flat buffers (no ``torch.cat`` before and no copy after the collective:
-    that was ~100 MB of extra traffic per step at config 5).  ``allreduce()`` sums the written buckets over the ranks
-    in place, asynchronously, and returns a ``wait()``; ``grad(p)`` is the (reduced) gradient of ``p``.
+    that was ~100 MB of extra traffic per step at config 5).  ``allreduce()`` sums the buckets over the ranks in place,
+    asynchronously, and returns a ``wait()``; ``grad(p)`` is the (reduced) gradient of ``p``.  A slot nobody wrote since
+    the last ``allreduce()`` is zeroed first (its parameter took no part in the step), so no stale, already-reduced
+    values go out again.  Parameters are registered as objects (weak references), not by address.  Call
+    ``zero_grad(set_to_none=True)`` (torch's default) between steps: a ``.grad`` left in place aliases the slot and is
+    then accumulated into, as torch would.
     RCCL over xGMI is a ring of point-to-point links (~150 GB/s each): a handful of >= 32 MB all-reduces runs at link
     rate where one call per filter (0.07 ... 19 MB, 11 filters) is latency-bound."""
 
@@ -357,7 +384,7 @@ class GradBuckets:
         if not params:
             raise ValueError("no parameters")
         dev, dt = params[0].device, params[0].dtype
-        self.flat, self._slots, self._written = [], {}, []
+        self.flat, self._slots, self._written = [], {}, set()
         sizes, cur = [], 0
         layout = []
         for p in params:
@@ -371,26 +398,33 @@ class GradBuckets:
             cur += n
         sizes.append(cur)
         self.flat = [torch.zeros(n, dtype=dt, device=dev) for n in sizes]
-        self._written = [False] * len(sizes)
         for k, off, shape, p in layout:
-            self._slots[p.data_ptr()] = (k, off, shape)
-            _grad_sinks[p.data_ptr()] = (self, k, off, shape)
+            if id(p) in self._slots:
+                raise ValueError("a parameter is listed twice")
+            self._slots[id(p)] = (weakref.ref(p), k, off, shape, p.numel())
+            _grad_sinks[id(p)] = (weakref.ref(p), self, k, off, shape)
 
     def grad(self, p: Tensor) -> Tensor:
-        k, off, shape = self._slots[p.data_ptr()]
-        return self.flat[k][off:off + p.numel()].view(shape)
+        ref, k, off, shape, n = self._slots[id(p)]
+        if ref() is not p:
+            raise KeyError("not a parameter of this GradBuckets")
+        return self.flat[k][off:off + n].view(shape)
 
     def release(self) -> None:
         """Unregister the parameters (their gradients are ordinary tensors again)."""
         for key in self._slots:
-            if _grad_sinks.get(key, (None,))[0] is self:
+            slot = _grad_sinks.get(key)
+            if slot is not None and slot[1] is self:
                 del _grad_sinks[key]
 
     def allreduce(self, process_group=None):
         """Sum every bucket over the data-parallel ranks, in place, asynchronously; returns ``wait()``, which makes
         the current stream wait for the results.  One rank / no process group: a no-op."""
         import torch.distributed as dist
-        self._written = [False] * len(self.flat)
+        for ref, k, off, shape, n in self._slots.values():
+            if (k, off) not in self._written:
+                self.flat[k][off:off + n].zero_()
+        self._written = set()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
             return lambda: None
         handles = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=process_group, async_op=True) for f in self.flat]

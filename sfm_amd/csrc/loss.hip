@@ -7,9 +7,13 @@
 // Between the two halves sits the only cross-GPU exchange of the data-parallel path:
 // an all-reduce of the S*(3N+1) fp64 partial sums; tf_ssim's
 // global mean (utils.py:573-575) is taken before its non-linear clip, so the sums
-// must be global before the backward coefficient of the SSIM part exists.  The stencil
-// kernel therefore writes the backward seeds in two parts (see loss_stencil.hip) and the
-// backward warp combines them with the coefficients loss_finalize_kernel derives.
+// must be global before the loss VALUE exists.  The backward coefficient of the SSIM part
+// needs only the global mask sums M(s, i) (loss_kv0, loss_common.h), and those are known
+// before the stencil runs: the splat tiles count their non-zero pixels where they write
+// Acc (msumt), loss_msum_fix_kernel corrects the tiles that received overflow
+// contributions, loss_msum_reduce_kernel adds them up.  Under data parallelism the S*N
+// mask sums are all-reduced while the gather-side stencil runs (sfm_loss_forward_warps /
+// _gather / _splat); the splat-side stencil then writes ONE combined seed plane.
 //
 // Per (scale s, source i), reference lines in SfMLearner_uni.py:
 //   G_i      = projective_inverse_warp(src_i, depth_s, pose_i, K, trans_si)          :120
@@ -24,7 +28,7 @@
 //   tgt [B,H,W,3]   src [B,H,W,3N]   depth [S,B,H,W]   trans [S,B,H,W,3N]
 //   G   [S,2,B,H,W,3]     gathered sources 0,1 (the only ones line 168 reads)
 //   Acc [S,N,B,H,W,4]     splat accumulators (sum g*rgb, sum g): one 16-B unit per pixel
-//   Hb  [2][S,N,B,H,W,4]  backward seeds per destination pixel, two parts: (hA[3], sum_c hA*Sp) and (hB[3], sum_c hB*Sp)
+//   Hb  [S,N,B,H,W,4]     backward seed per destination pixel: (h[3], sum_c h*Sp), h = hA + kV0 hB
 //   dG  [S,2,B,H,W,3]     backward: dL/dG_i for gloss = 1
 #include "loss_common.h"
 #include <cstdlib>
@@ -196,13 +200,15 @@ __global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_t
                                                                  float step_x, float step_y, int tiles_x, int tiles_y,
                                                                  const int4* __restrict__ shift, float* __restrict__ G,
                                                                  float* __restrict__ Acc, float* __restrict__ Ovf,
-                                                                 int* __restrict__ flags) {
+                                                                 int* __restrict__ flags, float* __restrict__ msumt,
+                                                                 unsigned short* __restrict__ ovl) {
   constexpr int TP = STW * STH;
   // planes: sum g*r, sum g*g, sum g*b, sum g.  fp64 on purpose: on gfx950 ds_add_f64 retires a wave
   // instruction in ~9 cycles while ds_add_f32 takes ~190 (profiles/r01_lds_atomic_microbench.txt);
   // the float -> double conversion is exact and the sums lose nothing before the final rounding.
   __shared__ double acc[4 * TP];
   __shared__ int4 tcache[kCacheW * kCacheH];
+  __shared__ float msred[kSplatThreads / 64];
   // 1-D grid in XCD-contiguous order: neighbouring tiles (overlapping scan windows) share an L2
   // ... and the N sources of one tile are consecutive: they read the same depth / tgt lines and the same
   // lines of the channel-interleaved trans and src ([.., 3N]), which then leave HBM once instead of N times
@@ -367,10 +373,20 @@ __global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_t
             atomicAdd(o + 0, tv.x * sw.g[q]);
             atomicAdd(o + 1, tv.y * sw.g[q]);
             atomicAdd(o + 2, tv.z * sw.g[q]);
-            atomicAdd(o + 3, sw.g[q]);
-            // the DESTINATION tile's flag: only its consumers (stencil strips over it, the backward tile that clears it)
-            // pay for the side accumulator.  Plain stores of 1: every racer writes the same value
-            if (!SOLO) flags[(size_t)img * (tiles_x * tiles_y) + ((unsigned)cy[q] / STH) * tiles_x + (unsigned)cx[q] / STW] = 1;
+            if constexpr (SOLO) {
+              atomicAdd(o + 3, sw.g[q]);
+            } else {
+              // The DESTINATION tile's counter: only its consumers (stencil strips over it, the backward tile that clears
+              // it, the mask-sum fix-up) pay for the side accumulator.  The weights are positive and Ovf starts at zero,
+              // so exactly one adder per pixel finds Ovf.w == 0 in front of a non-zero weight of its own: that one lists
+              // the pixel (an add of an underflowed weight 0 changes nothing and lists nothing).
+              const float oldw = atomicAdd(o + 3, sw.g[q]);
+              if (oldw == 0.0f && sw.g[q] != 0.0f) {
+                const size_t dt = (size_t)img * (tiles_x * tiles_y) + ((unsigned)cy[q] / STH) * tiles_x + (unsigned)cx[q] / STW;
+                const int slot = atomicAdd(&flags[dt], 1);  // < TP: one entry per pixel of the tile at most
+                ovl[dt * TP + slot] = (unsigned short)(((unsigned)cy[q] % STH) * STW + (unsigned)cx[q] % STW);
+              }
+            }
           }
       }
     }
@@ -385,6 +401,9 @@ __global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_t
   }
   __syncthreads();
   float* __restrict__ accg = Acc + (size_t)img * HW * 4;
+  float ms = 0.0f;  // this thread's share of the tile's mask sum (loss_kv0): its pixels share one column
+  const float wxq = SOLO ? 0.0f : mask_axis_weight(x0 + ((int)threadIdx.x & (STW - 1)), d.W);
+  static_assert(kSplatThreads % STW == 0, "a thread's pixels share their column");
   for (int k = threadIdx.x; k < TP; k += kSplatThreads) {
     const int u = x0 + (k & (STW - 1)), v = y0 + (k / STW);
     if (u < x1 && v < y1) {
@@ -397,10 +416,73 @@ __global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_t
           atomicAdd(o + 3, (float)acc[3 * TP + k]);
         }
       } else {
-        *reinterpret_cast<float4*>(o) = make_float4((float)acc[k], (float)acc[TP + k], (float)acc[2 * TP + k], (float)acc[3 * TP + k]);
+        const float4 a4 = make_float4((float)acc[k], (float)acc[TP + k], (float)acc[2 * TP + k], (float)acc[3 * TP + k]);
+        *reinterpret_cast<float4*>(o) = a4;
+        ms += nz_count(a4.x, a4.y, a4.z, a4.w) * (wxq * mask_axis_weight(v, d.H));
       }
     }
   }
+  if constexpr (!SOLO) {
+    ms = wave_sum_dpp_lane63(ms);
+    if ((threadIdx.x & 63) == 63) msred[threadIdx.x >> 6] = ms;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kSplatThreads / 64; ++k) t += msred[k];
+      msumt[(size_t)img * (tiles_x * tiles_y) + ty * tiles_x + tx] = t;
+    }
+  }
+}
+
+// The mask-sum share of a tile that received overflow contributions: its Acc alone was not the final accumulator when
+// the tile's owner counted the non-zero pixels.  One wave per (image, tile); exits at once unless the tile's counter is
+// raised, else walks the listed pixels (each once) and adds [nz(Acc + Ovf) - nz(Acc)] * wgt to the tile's share.
+__global__ __launch_bounds__(kBlock) void loss_msum_fix_kernel(const float* __restrict__ Acc, const float* __restrict__ Ovf,
+                                                              const int* __restrict__ flags,
+                                                              const unsigned short* __restrict__ ovl,
+                                                              float* __restrict__ msumt, int H, int W, int tiles_x,
+                                                              int ntile, long n_tiles_all) {
+  constexpr int TP = STW * STH;
+  const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (w >= n_tiles_all) return;
+  const int cnt = min(flags[w], TP);
+  if (cnt == 0) return;
+  const int lane = threadIdx.x & 63;
+  const long img = w / ntile;
+  const int tile = (int)(w - img * ntile);
+  const int x0 = (tile % tiles_x) * STW, y0 = (tile / tiles_x) * STH;
+  const float4* __restrict__ a = reinterpret_cast<const float4*>(Acc) + (size_t)img * H * W;
+  const float4* __restrict__ o = reinterpret_cast<const float4*>(Ovf) + (size_t)img * H * W;
+  float dsum = 0.0f;
+  for (int e = lane; e < cnt; e += 64) {
+    const int l = ovl[(size_t)w * TP + e];
+    const int u = x0 + (l & (STW - 1)), v = y0 + l / STW;
+    const size_t p = (size_t)v * W + u;
+    const float4 av = a[p], ov = o[p];
+    const float before = nz_count(av.x, av.y, av.z, av.w);
+    const float after = nz_count(av.x + ov.x, av.y + ov.y, av.z + ov.z, av.w + ov.w);  // the stencil's Acc + Ovf
+    dsum += (after - before) * (mask_axis_weight(u, W) * mask_axis_weight(v, H));
+  }
+  dsum = wave_sum_dpp_lane63(dsum);
+  if (lane == 63) msumt[w] += dsum;
+}
+
+// msumt -> msum[S*N] (fp64; the addends are fp32 values of one magnitude, so the fp64 sum is exact whatever the order).
+// grid: S*N blocks; the B * ntile tiles of (scale, source) are contiguous.
+__global__ __launch_bounds__(kBlock) void loss_msum_reduce_kernel(const float* __restrict__ msumt, long per,
+                                                                 double* __restrict__ msum) {
+  __shared__ double red[kBlock];
+  const float* __restrict__ m = msumt + (size_t)blockIdx.x * per;
+  double acc = 0.0;
+  for (long k = threadIdx.x; k < per; k += kBlock) acc += (double)m[k];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) msum[blockIdx.x] = red[0];
 }
 
 // Zeroes the side accumulator under the raised flags (forward-only steps).  grid (tiles per image, S*N*B).
@@ -454,18 +536,8 @@ __global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ finalize
-// partials (global sums) -> loss and the coefficient the backward warp scales the SSIM part of Hb with:
-// kV(s, i) = (1 - alpha) (M / n) (-1/2) [clip passes] / n   (d/dSp of (1-alpha) mean(m) clip((1 - V/n)/2, 0, 1)).
-// Every workgroup of the backward evaluates this: products with 1 / n instead of fp64 divisions (a V * (1/n) that differs
-// from V / n in the last bit of a double rounds to the same float except on an exact tie; `pass` only matters when the
-// mean SSIM leaves [-1, 1], which it cannot).
-__device__ __forceinline__ float loss_kv(const double* __restrict__ partials, int N, int s, int i, double inv_n) {
-  const int nterm = 3 * N + 1;
-  const double M = partials[s * nterm + 3 * i + 1], V = partials[s * nterm + 3 * i + 2];
-  const float h = (1.0f - (float)(V * inv_n)) / 2.0f;
-  const double pass = (h >= 0.0f && h <= 1.0f) ? 1.0 : 0.0;
-  return (float)((1.0 - (double)kAlpha) * (M * inv_n) * (-0.5) * pass * inv_n);
-}
+// partials (global sums) -> loss.  (The backward coefficient of the SSIM part, loss_kv0 in loss_common.h, is folded
+// into the seeds by the splat-side stencil.)
 
 __device__ __forceinline__ float loss_value(const double* __restrict__ partials, int S, int N, double n_elem,
                                             const double* __restrict__ e_sums = nullptr) {
@@ -524,7 +596,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
                                                                const float* __restrict__ Hb,
                                                                const float* __restrict__ dG,
                                                                const double* __restrict__ partials, double n_elem,
-                                                               double inv_n, float gl, int n_extra,
+                                                               float gl, int n_extra,
                                                                float* __restrict__ loss_out, LossDims d,
                                                                float step_x, float step_y, int tiles_x, int tiles_y,
                                                                float* __restrict__ d_depth,
@@ -557,14 +629,12 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
     for (int k = 0; k < n_extra; ++k) l += (float)partials[d.S * (3 * NT + 1) + k];  // other terms of total_loss (fp32 adds)
     *loss_out = l;
   }
-  const size_t hb_plane = (size_t)d.S * NT * d.B * HW * 4;
   Pose ps[N];
-  float kv[N], dp[N][12];
+  float dp[N][12];
   bool clr[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     ps[i] = load_pose(params + ((size_t)(i_base + i) * d.B + b) * SFM_PARAM_STRIDE);
-    kv[i] = gl * loss_kv(partials, NT, s, i_base + i, inv_n);  // wave-uniform (scalar loads)
     // BTW == STW and BTH divides STH: this tile lies inside splat tile (y0 / STH, x0 / STW)
     clr[i] = flags[((size_t)(s * NT + i_base + i) * d.B + b) * (tiles_x * ((d.H + STH - 1) / STH)) + (y0 / STH) * tiles_x + x0 / STW] != 0;
 #pragma unroll
@@ -651,7 +721,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
       Corners c[kPair];
       int idx[kPair][4];
       f3 ta[kPair][4], go[kPair];
-      float4 ha[kPair][4], hv[kPair][4];
+      float4 ha[kPair][4];
       // phase A: geometry of the pair, addresses of every gather
 #pragma unroll
       for (int j = 0; j < kPair; ++j) {
@@ -671,7 +741,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
         const size_t simg = ((size_t)s * NT + ig) * d.B + b;
         // this kernel runs after the last reader of Ovf: restore the all-zero invariant where it was used
         if (clr[i]) reinterpret_cast<float4*>(Ovf + simg * HW * 4)[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* hb = Hb + simg * HW * 4;  // part A; part B one plane further
+        const float* hb = Hb + simg * HW * 4;
         if (GATHERED) {
           const float* sbase = src + img * C3 + 3 * ig;
 #pragma unroll
@@ -679,10 +749,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
           go[j] = ld3(dG + ((((size_t)s * NG + ig) * d.B + b) * HW + p) * 3);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ha[j][q] = *reinterpret_cast<const float4*>(hb + (size_t)idx[j][q] * 4);
-          hv[j][q] = *reinterpret_cast<const float4*>(hb + hb_plane + (size_t)idx[j][q] * 4);
-        }
+        for (int q = 0; q < 4; ++q) ha[j][q] = *reinterpret_cast<const float4*>(hb + (size_t)idx[j][q] * 4);
       }
       // phase C: chain rule
 #pragma unroll
@@ -703,8 +770,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float da = ((ha[j][q].x * tv.x + ha[j][q].y * tv.y) + ha[j][q].z * tv.z) - ha[j][q].w;
-          const float dv = ((hv[j][q].x * tv.x + hv[j][q].y * tv.y) + hv[j][q].z * tv.z) - hv[j][q].w;
-          dgk[q] = (gl * da + kv[i] * dv) * sw.g[q];
+          dgk[q] = (gl * da) * sw.g[q];
         }
         gx_ += -(dgk[0] + dgk[1]) * sw.dx0 + (dgk[2] + dgk[3]) * sw.dx1;
         gy_ += -(dgk[0] + dgk[2]) * sw.dy0 + (dgk[1] + dgk[3]) * sw.dy1;
@@ -799,7 +865,7 @@ void loss_warp_bwd_kernel(const float* __restrict__ tgt,
 // Optional measurement aid for bench.py: when enabled, the two loss entry points bracket
 // each launch with HIP events on the caller's stream.  Off by default (no events, no
 // overhead); process-wide, not thread-safe - a bench facility, not part of the data path.
-enum { ST_SHIFT = 0, ST_WARP_FWD, ST_STENCIL, ST_REDUCE, ST_FINALIZE, ST_WARP_BWD, ST_POSE_GRAD, ST_COUNT };
+enum { ST_SHIFT = 0, ST_WARP_FWD, ST_STENCIL, ST_REDUCE, ST_FINALIZE, ST_WARP_BWD, ST_POSE_GRAD, ST_MSUM, ST_COUNT };
 static bool g_prof_on = false;
 static hipEvent_t g_ev[ST_COUNT][2];
 static bool g_ev_used[ST_COUNT];
@@ -871,7 +937,7 @@ bool launch_splat_solo(const float* img, const float* depth, const float* trans,
                      kReachMax);
   hipLaunchKernelGGL((loss_splat_tile_kernel<false, true>), dim3((unsigned)n), dim3(kSplatThreads), 0, stream, img,
                      (const float*)nullptr, depth, trans, PyrMaps{}, params, d, sfm_lin_step(W), sfm_lin_step(H), tx, ty, shift,
-                     (float*)nullptr, acc, acc, (int*)nullptr);
+                     (float*)nullptr, acc, acc, (int*)nullptr, (float*)nullptr, (unsigned short*)nullptr);
   return true;
 }
 }  // namespace sfm
@@ -888,6 +954,22 @@ extern "C" int sfm_loss_num_partials(int B, int H, int W, int S, int N) {
   return S * (3 * N + 1);
 }
 
+extern "C" int sfm_loss_workspace_region(int B, int H, int W, int S, int N, int which, long long* offset, long long* count) {
+  LossDims d{B, H, W, S, N};
+  if (!offset || !count || !dims_ok(d)) return SFM_ERR_ARG;
+  const LossWs w = loss_layout(d).w;
+  const long long acc = (long long)S * N * B * H * W * 4;
+  switch (which) {
+    case 0: *offset = (long long)w.Acc; *count = acc; break;
+    case 1: *offset = (long long)w.Ovf; *count = acc; break;
+    case 2: *offset = (long long)w.Hb; *count = acc; break;
+    case 3: *offset = (long long)w.flags; *count = w.n_flags; break;
+    case 4: *offset = (long long)w.msum; *count = 2LL * S * N; break;
+    default: return SFM_ERR_ARG;
+  }
+  return SFM_OK;
+}
+
 // Establishes the invariant both calls below rely on and restore: the side accumulator Ovf and
 // the per-image overflow flags are all zero between steps.  Call once on a fresh workspace (and
 // again after a failed call).
@@ -902,24 +984,35 @@ extern "C" int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, in
   return e == hipSuccess ? SFM_OK : (int)e;
 }
 
-// phases of the forward: 1 = tile_shift + both warps + splat-side stencil + its 3N sums per scale,
-// 2 = gather-side stencil + the min-reprojection sum per scale, 3 = everything in the plain order
+// phases of the forward (any subset, run in this order):
+//   kPhaseWarps   tile_shift + both warps (Acc, G, the tiles' mask-sum shares) + the mask sums M(s, i) -> msum_out
+//   kPhaseGather  gather-side stencil (min-reprojection term; dG)
+//   kPhaseSplat   splat-side stencil (masked L1 + SSIM terms; Hb with kV0 from the GLOBAL mask sums msum_in) + the
+//                 reduction of every per-wave sum -> partials (so kPhaseGather must have run before it)
 // pm: the prediction pyramid the warps read (then depth / trans are unused and may be null), or null = depth / trans
-// are the maps already resized to HxW, stacked over the scales
+// are the maps already resized to HxW, stacked over the scales.  msum_out / msum_in null: the workspace's own slot (the
+// single-device step, where this rank's mask sums are the global ones).
+constexpr int kPhaseWarps = 1, kPhaseGather = 2, kPhaseSplat = 4, kPhaseAll = 7;
 static int loss_forward_phases(int phases, const float* tgt, const float* src, const float* depth, const float* trans,
                                const PyrMaps* pm, const float* params, float* ws, int B, int H, int W, int S, int N,
-                               long long n_elem_global, int need_grad, double* partials, double* e_out, void* stream_) {
+                               long long n_elem_global, int need_grad, double* msum_out, const double* msum_in,
+                               double* partials, void* stream_) {
   LossDims d{B, H, W, S, N};
-  if (!tgt || !src || (!pm && (!depth || !trans)) || !params || !ws || !partials || n_elem_global <= 0 || !dims_ok(d))
-    return SFM_ERR_ARG;
+  if (!ws || !dims_ok(d)) return SFM_ERR_ARG;
+  if ((phases & kPhaseWarps) && (!tgt || !src || (!pm && (!depth || !trans)) || !params)) return SFM_ERR_ARG;
+  if ((phases & kPhaseGather) && (!tgt || n_elem_global <= 0)) return SFM_ERR_ARG;
+  if ((phases & kPhaseSplat) && (!src || !partials || n_elem_global <= 0)) return SFM_ERR_ARG;
   const PyrMaps pmv = pm ? *pm : PyrMaps{};
   hipStream_t stream = (hipStream_t)stream_;
   const LossLayout l = loss_layout(d);
   const LossWs& w = l.w;
   int4* shift = reinterpret_cast<int4*>(ws + w.shift);
   int* flags = reinterpret_cast<int*>(ws + w.flags);
+  float* msumt = ws + w.msumt;
+  unsigned short* ovl = reinterpret_cast<unsigned short*>(ws + w.ovl);
+  double* msum_ws = reinterpret_cast<double*>(ws + w.msum);
   int rc;
-  if (phases & 1) {
+  if (phases & kPhaseWarps) {
     { StageTimer t(ST_SHIFT, stream);
     const long n = (long)w.n_img * w.stiles_x * w.stiles_y;
     const dim3 grid((unsigned)((n * 16 + kBlock - 1) / kBlock));
@@ -933,35 +1026,33 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
     const dim3 grid((unsigned)((long)w.stiles_x * w.stiles_y * w.n_img));
     if (pm)
       hipLaunchKernelGGL(loss_splat_tile_kernel<true>, grid, dim3(kSplatThreads), 0, stream, tgt, src, depth, trans, pmv, params, d,
-                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf, flags);
+                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf, flags,
+                         msumt, ovl);
     else
       hipLaunchKernelGGL(loss_splat_tile_kernel<false>, grid, dim3(kSplatThreads), 0, stream, tgt, src, depth, trans, pmv, params, d,
-                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf, flags); }
+                         sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf, flags,
+                         msumt, ovl); }
+    { StageTimer t(ST_MSUM, stream);
+    const int ntile = w.stiles_x * w.stiles_y;
+    hipLaunchKernelGGL(loss_msum_fix_kernel, dim3((unsigned)((w.n_flags + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                       stream, ws + w.Acc, ws + w.Ovf, flags, ovl, msumt, H, W, w.stiles_x, ntile, w.n_flags);
+    hipLaunchKernelGGL(loss_msum_reduce_kernel, dim3(S * N), dim3(kBlock), 0, stream, msumt, (long)B * ntile,
+                       msum_out ? msum_out : msum_ws); }
     rc = sfm_last_error();
     if (rc) return rc;
   }
+  if (!(phases & (kPhaseGather | kPhaseSplat))) return SFM_OK;
   StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, w.stiles_x, w.stiles_y, ws + w.Hb, ws + w.dG, ws + w.wavep, d, l.sp,
-                (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global)};
-  if (phases == 3) {
-    { StageTimer t(ST_STENCIL, stream);
-    rc = launch_loss_stencil(a, need_grad != 0, kStencilGather | kStencilSplat, stream);
-    if (rc) return rc; }
-    { StageTimer t(ST_REDUCE, stream);
+                (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global),
+                msum_in ? msum_in : msum_ws, 1.0 / (double)n_elem_global};
+  { StageTimer t(ST_STENCIL, stream);
+  rc = launch_loss_stencil(a, need_grad != 0, ((phases & kPhaseGather) ? kStencilGather : 0) | ((phases & kPhaseSplat) ? kStencilSplat : 0),
+                           stream);
+  if (rc) return rc; }
+  if (phases & kPhaseSplat) {
+    StageTimer t(ST_REDUCE, stream);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 3 * N + 1), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials, 0,
-                       (double*)nullptr); }
-    return sfm_last_error();
-  }
-  if (phases & 1) {
-    rc = launch_loss_stencil(a, need_grad != 0, kStencilSplat, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 3 * N), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials, 0,
                        (double*)nullptr);
-  }
-  if (phases & 2) {
-    if (!e_out) return SFM_ERR_ARG;
-    rc = launch_loss_stencil(a, need_grad != 0, kStencilGather, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 1), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials, 3 * N, e_out);
   }
   return sfm_last_error();
 }
@@ -969,37 +1060,36 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
 extern "C" int sfm_loss_forward(const float* tgt, const float* src, const float* depth, const float* trans,
                                 const float* params, float* ws, int B, int H, int W, int S, int N,
                                 long long n_elem_global, int need_grad, double* partials, void* stream_) {
-  return loss_forward_phases(3, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, need_grad,
-                             partials, nullptr, stream_);
+  return loss_forward_phases(kPhaseAll, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, need_grad,
+                             nullptr, nullptr, partials, stream_);
 }
 
-// The forward in two halves, for a data-parallel step that hides its collectives:
-// _splat writes the 3N splat-side sums of every scale into partials (the [S][3N+1] layout; the min-reprojection
-// slots are left untouched - zero them once), _gather the min-reprojection sums into e_sums[S].  The splat-side
-// all-reduce then runs under the gather-side stencil, the e_sums all-reduce under sfm_loss_backward (which needs only
-// the splat-side sums for the gradients), and sfm_loss_value gives the loss once both have landed.
-extern "C" int sfm_loss_forward_splat(const float* tgt, const float* src, const float* depth, const float* trans,
-                                      const float* params, float* ws, int B, int H, int W, int S, int N,
-                                      long long n_elem_global, int need_grad, double* partials, void* stream_) {
-  return loss_forward_phases(1, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, need_grad,
-                             partials, nullptr, stream_);
+// The forward in three calls, for the data-parallel step (same kernels as sfm_loss_forward):
+//   _warps   both warps and this rank's mask sums msum[S*N] (fp64)
+//   [all-reduce (sum) of msum over the ranks, on the communication stream ...]
+//   _gather  [... while] the gather-side stencil runs
+//   _splat   the splat-side stencil with the GLOBAL mask sums, then every partial sum -> partials[S*(3N+1)]
+//   [all-reduce (sum) of partials]  ->  sfm_loss_backward
+extern "C" int sfm_loss_forward_warps(const float* tgt, const float* src, const float* depth, const float* trans,
+                                      const float* params, float* ws, int B, int H, int W, int S, int N, double* msum,
+                                      void* stream_) {
+  if (!msum) return SFM_ERR_ARG;
+  return loss_forward_phases(kPhaseWarps, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, 0, 1, msum, nullptr,
+                             nullptr, stream_);
 }
 
-extern "C" int sfm_loss_forward_gather(const float* tgt, const float* src, const float* depth, const float* trans,
-                                       const float* params, float* ws, int B, int H, int W, int S, int N,
-                                       long long n_elem_global, int need_grad, double* partials, double* e_sums,
-                                       void* stream_) {
-  return loss_forward_phases(2, tgt, src, depth, trans, nullptr, params, ws, B, H, W, S, N, n_elem_global, need_grad,
-                             partials, e_sums, stream_);
+extern "C" int sfm_loss_forward_gather(const float* tgt, float* ws, int B, int H, int W, int S, int N,
+                                       long long n_elem_global, int need_grad, void* stream_) {
+  return loss_forward_phases(kPhaseGather, tgt, nullptr, nullptr, nullptr, nullptr, nullptr, ws, B, H, W, S, N, n_elem_global,
+                             need_grad, nullptr, nullptr, nullptr, stream_);
 }
 
-// loss (one float) from the global sums; e_sums (may be NULL): the min-reprojection sums if they were reduced apart
-extern "C" int sfm_loss_value(const double* partials, const double* e_sums, int S, int N, long long n_elem_global,
-                              float* loss_out, void* stream_) {
-  if (!partials || !loss_out || S < 1 || N < 2 || N > kMaxSrc || n_elem_global <= 0) return SFM_ERR_ARG;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, partials, S, N, (double)n_elem_global,
-                     loss_out, e_sums, 0);
-  return sfm_last_error();
+extern "C" int sfm_loss_forward_splat(const float* src, float* ws, int B, int H, int W, int S, int N,
+                                      long long n_elem_global, int need_grad, const double* msum_global, double* partials,
+                                      void* stream_) {
+  if (!msum_global) return SFM_ERR_ARG;
+  return loss_forward_phases(kPhaseSplat, nullptr, src, nullptr, nullptr, nullptr, nullptr, ws, B, H, W, S, N, n_elem_global,
+                             need_grad, nullptr, msum_global, partials, stream_);
 }
 
 // partials: the (all-reduced) sums of sfm_loss_forward; n_elem_global = B_global*H*W*3 (the value
@@ -1016,7 +1106,8 @@ static int loss_backward_common(const float* tgt, const float* src, const float*
     return SFM_ERR_ARG;
   if (need_grad && (!pose || !K || !d_depth || !d_trans || !d_pose)) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  const LossWs w = loss_layout(d).w;
+  const LossLayout ll = loss_layout(d);
+  const LossWs& w = ll.w;
   const PyrMaps pmv = pm ? *pm : PyrMaps{};
   int* flags = reinterpret_cast<int*>(ws + w.flags);
   if (!need_grad) {  // forward-only step: the loss, and restore the Ovf / flags invariant here
@@ -1028,11 +1119,19 @@ static int loss_backward_common(const float* tgt, const float* src, const float*
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_flags * sizeof(int), stream);
     return e != hipSuccess ? (int)e : sfm_last_error();
   }
+  { // seeds written under a clip that turned out not to pass (degenerate inputs only): rewritten before they are read
+    StageTimer t(ST_FINALIZE, stream);
+    StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, w.stiles_x, w.stiles_y, ws + w.Hb, ws + w.dG, ws + w.wavep, d, ll.sp,
+                  (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global),
+                  reinterpret_cast<const double*>(ws + w.msum), 1.0 / (double)n_elem_global};
+    const int rc0 = launch_loss_stencil_redo(a, partials, stream);
+    if (rc0) return rc0;
+  }
   { StageTimer t(ST_WARP_BWD, stream);
   const dim3 grid((unsigned)((long)S * B * w.nblk_bwd));
 #define SFM_LAUNCH_BWD_P(NSRC, IBASE, NTC, PYR)                                                                          \
   hipLaunchKernelGGL((loss_warp_bwd_kernel<NSRC, (IBASE) == 0, NTC, IBASE, PYR>), grid, dim3(kBlock), 0, stream, tgt, src, depth,  \
-                     trans, pmv, params, ws + w.Hb, ws + w.dG, partials, (double)n_elem_global, 1.0 / (double)n_elem_global,     \
+                     trans, pmv, params, ws + w.Hb, ws + w.dG, partials, (double)n_elem_global,                                     \
                      gloss, n_extra, loss_out, d, sfm_lin_step(W), sfm_lin_step(H), w.btiles_x, w.btiles_y, d_depth, d_trans,       \
                      ws + w.dPp, ws + w.Ovf, flags)
 #define SFM_LAUNCH_BWD(NSRC, IBASE, NTC)                                   \
@@ -1094,7 +1193,19 @@ extern "C" int sfm_loss_forward_pyr(const float* tgt, const float* src, const fl
   PyrMaps pm;
   const int rc = fill_pyr_maps(pm, depth_s, trans_s, h, w, S, H, W);
   if (rc) return rc;
-  return loss_forward_phases(3, tgt, src, nullptr, nullptr, &pm, params, ws, B, H, W, S, N, n_elem_global, need_grad, partials,
+  return loss_forward_phases(kPhaseAll, tgt, src, nullptr, nullptr, &pm, params, ws, B, H, W, S, N, n_elem_global, need_grad,
+                             nullptr, nullptr, partials, stream_);
+}
+
+// sfm_loss_forward_warps fed with the pyramid (the other two calls of the data-parallel forward read no prediction map)
+extern "C" int sfm_loss_forward_warps_pyr(const float* tgt, const float* src, const float* const* depth_s,
+                                          const float* const* trans_s, const int* h, const int* w, const float* params,
+                                          float* ws, int B, int H, int W, int S, int N, double* msum, void* stream_) {
+  if (!msum) return SFM_ERR_ARG;
+  PyrMaps pm;
+  const int rc = fill_pyr_maps(pm, depth_s, trans_s, h, w, S, H, W);
+  if (rc) return rc;
+  return loss_forward_phases(kPhaseWarps, tgt, src, nullptr, nullptr, &pm, params, ws, B, H, W, S, N, 0, 1, msum, nullptr,
                              nullptr, stream_);
 }
 
@@ -1134,7 +1245,7 @@ extern "C" int sfm_prof_stages(void) { return ST_COUNT; }
 
 // Adds the elapsed milliseconds of the last step's launches into ms[ST_COUNT]; the
 // caller must have synchronised the stream.  Stage order: tile_shift, warp_fwd, stencil,
-// reduce, finalize, warp_bwd, pose_grad.
+// reduce, finalize (forward-only steps) / seed redo check, warp_bwd, pose_grad, mask sums.
 extern "C" int sfm_prof_read(float* ms) {
   if (!g_ev_made || !ms) return SFM_ERR_ARG;
   for (int i = 0; i < ST_COUNT; ++i) {

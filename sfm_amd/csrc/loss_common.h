@@ -91,11 +91,15 @@ static inline StencilPlan stencil_plan(const LossDims& d, int rows_override, int
 // ---- workspace map (floats) -------------------------------------------------------------
 //   Acc [S,N,B,H,W,4]   splat accumulators (sum g*rgb, sum g), one 16-byte unit per pixel
 //   Ovf [S,N,B,H,W,4]   overflow side accumulator (all zero between steps)
-//   Hb  [2][S,N,B,H,W,4] backward: per destination pixel the two parts (hA[3], sum_c hA*Sp) and (hB[3], sum_c hB*Sp)
+//   Hb  [S,N,B,H,W,4]   backward seed per destination pixel: (h[3], sum_c h*Sp), h = hA + kV0 * hB (loss_stencil.hip)
 //   G   [S,2,B,H,W,3]   gathered sources 0,1
 //   dG  [S,2,B,H,W,3]   backward: dL/dG_i (gloss = 1)
 //   wavep [n_waves][4]  per-wave partial sums of the stencil kernel
 //   dPp [S,N,B,nblk,12] dL/dP block partials of the backward warp
+//   msumt [n_img][tiles] per splat tile: sum of nz(q) * wgt(q) = the tile's share of the mask sum M (see loss_kv0)
+//   msum  [S*N] fp64     M per (scale, source) on this rank (the single-device step reads it back as the global one)
+//   ovl [n_img][tiles][STW*STH] uint16: per splat tile, the pixels (index inside the tile) that received overflow
+//                        contributions - each listed once, by the adder that found Ovf.w == 0; `flags` holds the count
 #ifndef SFM_STH
 #define SFM_STH 32
 #endif
@@ -112,9 +116,9 @@ constexpr int kLossPPT = BTW * BTH / kBlock;  // pixels per thread in the backwa
 static_assert(BTW == STW && STH % BTH == 0, "a backward tile lies inside one splat tile (per-tile overflow flags)");
 
 struct LossWs {
-  size_t G, Acc, Ovf, Hb, dG, wavep, dPp, coef, shift, flags, total;
+  size_t G, Acc, Ovf, Hb, dG, wavep, dPp, coef, msumt, msum, ovl, shift, flags, total;
   int nblk_bwd, btiles_x, btiles_y, stiles_x, stiles_y, n_img;
-  long n_flags;  // one overflow flag per (image, splat tile)
+  long n_flags;  // one overflow counter per (image, splat tile): 0 = the tile's Acc is complete
 };
 
 static inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
@@ -132,14 +136,17 @@ static inline LossWs loss_ws(const LossDims& d, const StencilPlan& sp) {
   size_t o = 0;
   w.Acc = o; o += (size_t)d.S * d.N * npx * 4;
   w.Ovf = o; o += (size_t)d.S * d.N * npx * 4;
-  w.Hb = o;  o += (size_t)d.S * d.N * npx * 8;
+  w.Hb = o;  o += (size_t)d.S * d.N * npx * 4;
   w.G = o;   o += up4((size_t)d.S * ng * npx * 3);
   w.dG = o;  o += up4((size_t)d.S * ng * npx * 3);
   w.wavep = o; o += up4((size_t)(sp.n_splat + sp.n_gather) * kWaveTerms);
   w.dPp = o; o += up4((size_t)d.S * d.N * d.B * w.nblk_bwd * 12);
   w.coef = o; o += 64;
-  w.shift = o; o += (size_t)w.n_img * w.stiles_x * w.stiles_y * 4;
   w.n_flags = (long)w.n_img * w.stiles_x * w.stiles_y;
+  w.msumt = o; o += up4((size_t)w.n_flags);
+  w.msum = o; o += up4((size_t)d.S * d.N * 2);            // doubles (every offset here is a multiple of 4 floats)
+  w.ovl = o; o += (size_t)w.n_flags * (STW * STH / 2);   // uint16 entries
+  w.shift = o; o += (size_t)w.n_img * w.stiles_x * w.stiles_y * 4;
   w.flags = o; o += up4((size_t)w.n_flags);
   w.total = o;
   return w;
@@ -160,10 +167,43 @@ struct StencilArgs {
   StencilPlan p;
   float kL1;  // alpha / n_elem_global          (coefficient of the masked L1 term, :149)
   float kE;   // 2 / n_elem_global              (coefficient of the min-reprojection term, :168)
+  const double* msum;  // [S*N] GLOBAL mask sums M(s, i) = sum m (all ranks), known before the splat-side stencil runs
+  double inv_n;        // 1 / n_elem_global
 };
+
+// Coefficient of the SSIM part of the splat-side seeds: d/dSp of (1 - alpha) mean(m) clip((1 - mean ssim) / 2, 0, 1)
+// (SfMLearner_uni.py:144, 149; utils.py:573-575) = kV0 * d ssim / dSp with kV0 = (1 - alpha) (M / n) (-1/2) / n while the
+// clip passes.  M = sum m = sum_q nz(q) wgt(q) (utils.py:478-479: m is the 3x3 SAME average of nz = 1 - [Sp == 0], so its
+// sum needs no window: wgt(q) = sum over the windows containing q of 1 / their in-bounds tap count, position only) is
+// taken where the splat tiles are written, BEFORE the stencil - so the stencil can write ONE combined seed plane
+// h = hA + kV0 hB instead of the two parts.  Whether the clip passes is only known after the stencil (it depends on the
+// global mean SSIM); it fails only for degenerate inputs (mean SSIM outside [-1, 1]); then the affected seeds are
+// rewritten with kV0 = 0 before the backward reads them (loss_stencil_splat_redo_kernel).
+__device__ __forceinline__ float loss_kv0(double M, double inv_n) {
+  return (float)((1.0 - (double)kAlpha) * (M * inv_n) * (-0.5) * inv_n);
+}
+__device__ __forceinline__ bool loss_clip_passes(double V, double inv_n) {
+  const float h = (1.0f - (float)(V * inv_n)) / 2.0f;
+  return h >= 0.0f && h <= 1.0f;
+}
+// sum over the 3-tap SAME windows (along one axis of n positions) that contain position q of 1 / (their in-bounds taps)
+__device__ __forceinline__ float mask_axis_weight(int q, int n) {
+  if (q >= 2 && q <= n - 3) return 1.0f;  // three full windows: fl(1/3) * 3 rounds to 1
+  float s = 0.0f;
+  for (int p = max(q - 1, 0); p <= min(q + 1, n - 1); ++p) s += 1.0f / (float)(min(p + 1, n - 1) - max(p - 1, 0) + 1);
+  return s;
+}
+// number of non-zero channels of Sp = acc.rgb / (acc.w + 1e-10) (utils.py:463, 470, 478), with the stencil's arithmetic
+__device__ __forceinline__ float nz_count(float r, float g, float b, float w) {
+  const float inv = __builtin_amdgcn_rcpf(w + 1e-10f);
+  return ((r * inv == 0.0f) ? 0.0f : 1.0f) + ((g * inv == 0.0f) ? 0.0f : 1.0f) + ((b * inv == 0.0f) ? 0.0f : 1.0f);
+}
 
 // loss_stencil.hip.  which: the gather side (min-reprojection term), the splat side (masked L1 + SSIM terms), or both
 constexpr int kStencilGather = 1, kStencilSplat = 2;
 int launch_loss_stencil(const StencilArgs& a, bool need_grad, int which, hipStream_t stream);
+// rewrites the seeds of every (scale, source) whose clip does not pass (global sums in partials) with kV0 = 0; exits at
+// once otherwise (the normal case)
+int launch_loss_stencil_redo(const StencilArgs& a, const double* partials, hipStream_t stream);
 
 }  // namespace sfm

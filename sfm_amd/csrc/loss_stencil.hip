@@ -3,11 +3,13 @@
 //
 // Why one pass is possible: the backward through  mean(m) * clip((1 - mean ssim(Sp, src)) / 2)
 // needs the GLOBAL sums M = sum m and V = sum ssim (utils.py:573-575 takes the mean before the
-// clip).  Everything downstream of this kernel is linear in dL/dSp, so the kernel writes the two
-// parts separately - hA (masked-L1 part, coefficient alpha/n known up front) and hB (SSIM part,
-// to be scaled by kV = (1-alpha) (M/n) (-1/2) [clip passes] / n once the sums are global) - and
-// the backward warp combines them.  The gather side (min-reprojection, :168) has no such
-// dependence: dL/dG is final here.
+// clip).  M is known before this kernel runs (it needs no window: loss_kv0 in loss_common.h; the
+// splat tiles count it, and under data parallelism it is all-reduced while the gather side runs),
+// so the seed of the masked-L1 part hA (coefficient alpha/n) and of the SSIM part hB (coefficient
+// kV0 = (1-alpha) (M/n) (-1/2) / n) leave as ONE plane h = hA + kV0 hB.  V only decides whether
+// the clip passes, which it does unless the mean SSIM leaves [-1, 1]; for that case the REDO form
+// of the kernel rewrites the seeds with kV0 = 0 once the sums are global (exits at once otherwise).
+// The gather side (min-reprojection, :168) has no such dependence: dL/dG is final here.
 //
 // Work decomposition: one WAVE owns a strip of 60 image columns (64 lanes, 2 halo lanes on each
 // side) and marches down `rows` image rows.  Horizontal neighbours come from the adjacent lanes
@@ -177,9 +179,8 @@ struct SplatWave {
   const float* __restrict__ ovf;
   const float* __restrict__ sp;
   float* __restrict__ hb;
-  size_t hb_plane;
   int C3;
-  float kL1;
+  float kL1, kV0;
   Taps taps;
   float P1[3][4], P0[3][4];  // vertical accumulators of the moments x, y, xx + yy, xy per channel
   float N1[3], N0[3];        // ... of the non-zero counts
@@ -269,19 +270,15 @@ struct SplatWave {
           for (int m = 0; m < 3; ++m) rr[ch][m] = vpush(C1[ch][m], C0[ch][m], hc[ch][m]);
         const int p = r - 2;
         if (own_col && p >= y0 && p < y1) {
-          float hA[3], hB[3], wA = 0.f, wB = 0.f;
+          float h[3], wh = 0.f;
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
             const float xq = X[S2][ch], yq = Y[S2][ch];
             const float g = rr[ch][0] + 2.0f * rr[ch][1] * xq + rr[ch][2] * yq;
-            hA[ch] = (kL1 * Mk[S2][ch] * sgn(xq - yq)) * Iv[S2];
-            hB[ch] = g * Iv[S2];
-            wA += hA[ch] * xq;
-            wB += hB[ch] * xq;
+            h[ch] = (kL1 * Mk[S2][ch] * sgn(xq - yq) + kV0 * g) * Iv[S2];
+            wh += h[ch] * xq;
           }
-          float* o = hb + ((size_t)p * d.W + gx) * 4;
-          *reinterpret_cast<float4*>(o) = make_float4(hA[0], hA[1], hA[2], wA);
-          *reinterpret_cast<float4*>(o + hb_plane) = make_float4(hB[0], hB[1], hB[2], wB);
+          *reinterpret_cast<float4*>(hb + ((size_t)p * d.W + gx) * 4) = make_float4(h[0], h[1], h[2], wh);
         }
       }
     }
@@ -293,8 +290,10 @@ struct SplatWave {
   }
 };
 
-template <bool GRAD>
-__device__ __forceinline__ void splat_item(const StencilArgs& a, long item, float* __restrict__ wavep_out) {
+// REDO: the seeds of one item again with kV0 = 0 (its clip did not pass); no sums are written
+template <bool GRAD, bool REDO = false>
+__device__ __forceinline__ void splat_item(const StencilArgs& a, long item, float* __restrict__ wavep_out,
+                                           const double* __restrict__ partials = nullptr) {
   SplatWave<GRAD> w;
   const LossDims d = a.d;
   w.d = d;
@@ -307,6 +306,9 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   Item it = split_item((long)(uw / un), a.p.strips, a.p.chunks);  // it.img = s * B + b here
   const int b = it.img % d.B, s_ = it.img / d.B;
   it.img = (s_ * d.N + i) * d.B + b;
+  if constexpr (REDO) {
+    if (loss_clip_passes(partials[s_ * (3 * d.N + 1) + 3 * i + 2], a.inv_n)) return;  // wave-uniform
+  }
   wavep_out += ((size_t)it.img * a.p.per_img + (size_t)it.chunk * a.p.strips + it.strip) * kWaveTerms;
   const int lane = threadIdx.x & 63;
   const int HW = d.H * d.W;
@@ -329,8 +331,8 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   }
   w.ovf = any_ovf ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;
   w.sp = a.src + (size_t)b * HW * w.C3 + 3 * i;
-  w.hb = a.Hb + (size_t)it.img * HW * 4;  // part A; part B one plane further
-  w.hb_plane = (size_t)d.S * d.N * d.B * HW * 4;
+  w.hb = a.Hb + (size_t)it.img * HW * 4;
+  w.kV0 = (GRAD && !REDO) ? loss_kv0(a.msum[s_ * d.N + i], a.inv_n) : 0.0f;
   const float nx = (float)(min(w.gx + 1, d.W - 1) - max(w.gx - 1, 0) + 1);
   // 1 / (taps of the 3x3 SAME window inside the image): k * fl(1/k) == 1 exactly for k = 4, 6, 9
   const float rc3 = 1.0f / (3.0f * nx), rc2 = 1.0f / (2.0f * nx), rc1 = 1.0f / nx;
@@ -361,6 +363,7 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
     if (r + 1 <= w.r_last) w.template step<1>(r + 1, rc3, rc2, rc1);
     if (r + 2 <= w.r_last) w.template step<2>(r + 2, rc3, rc2, rc1);
   }
+  if constexpr (REDO) return;
   const float sA = wave_sum_dpp_lane63(w.sA), sM = wave_sum_dpp_lane63(w.sM), sV = wave_sum_dpp_lane63(w.sV);
   if (lane == 63) *reinterpret_cast<float4*>(wavep_out) = make_float4(sA, sM, sV, 0.f);
 }
@@ -504,7 +507,28 @@ __global__ __launch_bounds__(kBlock) SFM_WPE_SPLAT void loss_stencil_splat_kerne
   if (w < a.p.n_splat) splat_item<GRAD>(a, w, a.wavep);  // the item computes its own slot
 }
 
+// The guard of the combined seed plane.  A small fixed grid: every wave first looks at the S*N global SSIM sums and
+// leaves if every clip passes (always, for real images); otherwise the waves share the items of the failing
+// (scale, source) pairs and rewrite their seeds with kV0 = 0.
+// One wave per workgroup: the item index is then a scalar from the start (blockIdx), with no v_readfirstlane next to the
+// inline-asm DPP blocks (tests/test_build_invariants.py).
+constexpr int kRedoWaves = 1024;
+__global__ __launch_bounds__(64) SFM_WPE_SPLAT void loss_stencil_splat_redo_kernel(StencilArgs a,
+                                                                                     const double* __restrict__ partials) {
+  const int nterm = 3 * a.d.N + 1;
+  bool any = false;
+  for (int k = 0; k < a.d.S * a.d.N; ++k)
+    any |= !loss_clip_passes(partials[(k / a.d.N) * nterm + 3 * (k % a.d.N) + 2], a.inv_n);
+  if (!any) return;
+  for (long w = blockIdx.x; w < a.p.n_splat; w += gridDim.x) splat_item<true, true>(a, w, a.wavep, partials);
+}
+
 }  // namespace
+
+int launch_loss_stencil_redo(const StencilArgs& a, const double* partials, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_stencil_splat_redo_kernel, dim3(kRedoWaves), dim3(64), 0, stream, a, partials);
+  return sfm_last_error();
+}
 
 // Both kernels go to the caller's stream, back to back.  Running them side by side (the gather side on a second stream,
 // forked and joined with events) was measured at c2 and is SLOWER: 116 us for the pair instead of 96 (gather 93 us

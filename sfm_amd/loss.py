@@ -9,10 +9,12 @@
     fused=False  the reference's op decomposition, each op a stand-alone HIP operator of
                  ``sfm_amd.utils`` / ``sfm_amd.pyramid`` chained by torch autograd.
 
-Data parallelism (SURVEY.md section 8e): the batch of snippets is sharded over ranks;
-the only exchange is one all-reduce of S*(3N+1) fp64 partial sums between the two
-halves of the fused pipeline (``process_group``), because tf_ssim's global mean is
-taken before its clip (utils.py:573-575).  Gradients are per-sample: no collective.
+Data parallelism: the batch of snippets is sharded over ranks.
+Two small exchanges per step: the S*N fp64 mask sums (``proj_src_mask``, utils.py:478-479;
+their global mean scales the SSIM term, SfMLearner_uni.py:144) are all-reduced on the
+communication stream while the gather-side stencil runs, and the S*(3N+1) fp64 partial sums
+between the two halves of the fused pipeline, because tf_ssim's global mean is taken before
+its clip (utils.py:573-575).  Gradients are per-sample: no collective.
 """
 from __future__ import annotations
 
@@ -57,12 +59,18 @@ class LossEngine:
     def overflow_state(self):
         """(number of raised overflow flags - one per (image, 64x32 splat tile) -, max |Ovf|): both 0 between steps
         (test / debug aid)."""
-        B, H, W, S, N = self.dims
-        n_acc = S * N * B * H * W * 4
-        ovf = self.ws[n_acc:2 * n_acc]                       # workspace map of csrc/loss.hip: Acc, Ovf, ...
-        n_flags = S * N * B * ((W + 63) // 64) * ((H + 31) // 32)
-        flags = self.ws[-((n_flags + 3) // 4 * 4):].view(torch.int32)[:n_flags]
+        ovf = self.region("Ovf")
+        flags = self.region("flags").view(torch.int32)
         return int((flags != 0).sum()), float(ovf.abs().max())
+
+    _REGIONS = {"Acc": 0, "Ovf": 1, "Hb": 2, "flags": 3, "msum": 4}
+
+    def region(self, name: str) -> Tensor:
+        """A view of one region of the workspace (test / debug aid; the map lives in csrc/loss_common.h)."""
+        B, H, W, S, N = self.dims
+        off, cnt = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        call("sfm_loss_workspace_region", B, H, W, S, N, self._REGIONS[name], ctypes.byref(off), ctypes.byref(cnt))
+        return self.ws[off.value:off.value + cnt.value]
 
     @staticmethod
     def _pyr_args(depth, trans):
@@ -70,13 +78,32 @@ class LossEngine:
         return (P._ptrs(depth), P._ptrs(trans), P._ints([t.shape[1] for t in trans]), P._ints([t.shape[2] for t in trans]))
 
     def forward_partials(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool = True,
-                         out: Optional[Tensor] = None) -> Tensor:
+                         out: Optional[Tensor] = None, process_group=None, dp: Optional[bool] = None,
+                         msum_allreduce=None) -> Tensor:
         """First half: both warps, the L1/SSIM stencil and the local partial sums.  ``n_elem_global`` =
         B_global*H*W*3 (the reduce_mean denominators are global under data parallelism).
         ``depth`` / ``trans``: the maps resized to HxW and stacked ([S,B,H,W], [S,B,H,W,3N]), or LISTS of the
-        pyramid's maps at their native sizes - the kernels then resize while loading (``sfm_loss_forward_pyr``)."""
+        pyramid's maps at their native sizes - the kernels then resize while loading (``sfm_loss_forward_pyr``).
+        With more than one rank in ``process_group`` (or in the default group when torch.distributed is initialised and
+        ``n_elem_global`` says the batch is larger than this rank's) the forward runs as three calls and the mask sums
+        are all-reduced beside the gather-side stencil (``forward_warps`` / ``forward_gather`` / ``forward_splat``).
+        ``dp``: force that sequence on (rehearsals with one rank) or off; ``msum_allreduce``: a callable that sums the
+        mask-sum tensor over the ranks in place and returns a work handle or None, in place of ``dist.all_reduce(...,
+        async_op=True)`` (rehearsal backends that cannot reduce device tensors)."""
         B, H, W, S, N = self.dims
         partials = out if out is not None else torch.empty(self.n_partials, dtype=torch.float64, device=self.device)
+        if dp if dp is not None else _world_size(process_group) > 1:
+            import torch.distributed as dist
+            msum = self.forward_warps(tgt, src, K, depth, pose, trans)
+            if msum_allreduce is not None:
+                work = msum_allreduce(msum)
+            else:
+                work = dist.all_reduce(msum, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+            self.forward_gather(tgt, n_elem_global, need_grad)
+            if work is not None:
+                work.wait()  # device tensors: the current stream waits for the collective, not the host
+            self.forward_splat(src, n_elem_global, need_grad, msum, partials)
+            return partials
         st = stream_of(tgt)
         call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
         if isinstance(depth, (list, tuple)):
@@ -86,6 +113,32 @@ class LossEngine:
             call("sfm_loss_forward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W, S,
                  N, int(n_elem_global), int(need_grad), ptr(partials), st)
         return partials
+
+    # the three calls of the data-parallel forward, one method each (the CPU test of the host sequence replaces them by
+    # the oracle: tests/test_dp_gloo.py)
+    def forward_warps(self, tgt, src, K, depth, pose, trans) -> Tensor:
+        """both warps; returns this rank's mask sums [S*N] (fp64), to be summed over the ranks"""
+        B, H, W, S, N = self.dims
+        st = stream_of(tgt)
+        msum = torch.empty(S * N, dtype=torch.float64, device=self.device)
+        call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
+        if isinstance(depth, (list, tuple)):
+            call("sfm_loss_forward_warps_pyr", ptr(tgt), ptr(src), *self._pyr_args(depth, trans), ptr(self.params),
+                 ptr(self.ws), B, H, W, S, N, ptr(msum), st)
+        else:
+            call("sfm_loss_forward_warps", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws),
+                 B, H, W, S, N, ptr(msum), st)
+        return msum
+
+    def forward_gather(self, tgt, n_elem_global: int, need_grad: bool) -> None:
+        B, H, W, S, N = self.dims
+        call("sfm_loss_forward_gather", ptr(tgt), ptr(self.ws), B, H, W, S, N, int(n_elem_global), int(need_grad),
+             stream_of(tgt))
+
+    def forward_splat(self, src, n_elem_global: int, need_grad: bool, msum_global: Tensor, partials: Tensor) -> None:
+        B, H, W, S, N = self.dims
+        call("sfm_loss_forward_splat", ptr(src), ptr(self.ws), B, H, W, S, N, int(n_elem_global), int(need_grad),
+             ptr(msum_global), ptr(partials), stream_of(src))
 
     def backward(self, tgt, src, K, depth, pose, trans, partials, n_elem_global: int, gloss: float = 1.0,
                  need_grad: bool = True, d_trans_into: Optional[Sequence[Tensor]] = None, n_extra: int = 0):
@@ -123,56 +176,8 @@ class LossEngine:
              ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
         return loss, d_depth, d_pose, d_trans
 
-    # the three extra calls of the overlapped data-parallel step, one method each (the CPU test of the host sequence
-    # replaces them by the oracle: tests/test_dp_gloo.py)
-    def forward_splat(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool, buf: Tensor) -> None:
-        B, H, W, S, N = self.dims
-        st = stream_of(tgt)
-        call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
-        call("sfm_loss_forward_splat", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
-             S, N, int(n_elem_global), int(need_grad), ptr(buf), st)
-
-    def forward_gather(self, tgt, src, K, depth, pose, trans, n_elem_global: int, need_grad: bool, buf: Tensor,
-                       e_sums: Tensor) -> None:
-        B, H, W, S, N = self.dims
-        call("sfm_loss_forward_gather", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H,
-             W, S, N, int(n_elem_global), int(need_grad), ptr(buf), ptr(e_sums), stream_of(tgt))
-
-    def loss_value(self, buf: Tensor, e_sums: Tensor, n_elem_global: int, loss: Tensor) -> None:
-        B, H, W, S, N = self.dims
-        call("sfm_loss_value", ptr(buf), ptr(e_sums), S, N, int(n_elem_global), ptr(loss), stream_of(buf))
-
-    def step_dp(self, tgt, src, K, depth, pose, trans, n_elem_global: int, process_group=None, need_grad: bool = True,
-                tail: Optional[Tensor] = None):
-        """One data-parallel step with both collectives hidden:
-
-            forward_splat -> all-reduce #1 (3N splat-side sums per scale [+ tail]) || forward_gather
-                          -> all-reduce #2 (min-reprojection sums)                 || backward
-                          -> loss value from the two reduced buffers
-
-        The gradients need only the splat-side sums (kV); the min-reprojection sums only enter the loss VALUE,
-        so their all-reduce can ride under the backward.  ``tail``: extra fp64 scalars summed over the ranks in
-        all-reduce #1 (the regulariser's share of the loss).  Returns (loss, d_depth, d_pose, d_trans, tail)."""
-        import torch.distributed as dist
-        B, H, W, S, N = self.dims
-        n_tail = 0 if tail is None else tail.numel()
-        buf = torch.zeros(self.n_partials + n_tail, dtype=torch.float64, device=self.device)
-        if n_tail:
-            buf[self.n_partials:] = tail
-        e_sums = torch.empty(S, dtype=torch.float64, device=self.device)
-        self.forward_splat(tgt, src, K, depth, pose, trans, n_elem_global, need_grad, buf)
-        h1 = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
-        self.forward_gather(tgt, src, K, depth, pose, trans, n_elem_global, need_grad, buf, e_sums)
-        h2 = dist.all_reduce(e_sums, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
-        h1.wait()  # the current stream waits for all-reduce #1 (not the host)
-        loss, d_depth, d_pose, d_trans = self.backward(tgt, src, K, depth, pose, trans, buf, n_elem_global, 1.0, need_grad)
-        h2.wait()
-        self.loss_value(buf, e_sums, n_elem_global, loss)
-        return loss, d_depth, d_pose, d_trans, (buf[self.n_partials:] if n_tail else None)
-
 
 _engines = {}
-_global_batch_cache = {}
 
 
 def _world_size(process_group=None) -> int:
@@ -203,12 +208,10 @@ def _evict_engine(eng: LossEngine) -> None:
 
 
 def global_batch(B_local: int, process_group=None, device=None) -> int:
-    """Total number of snippets over all ranks (each rank may hold a different count).
-
-    One all-reduce and ONE host synchronisation (``.item()``) the first time a (process group, local count) pair is
-    seen; the answer is cached after that, so a training loop pays it once, not per step.  The cache assumes a fixed
-    sharding: if the local counts change from step to step differently on different ranks, pass ``global_batch_size``
-    to ``multi_scale_loss`` instead (a rank that hits the cache while another misses it would skip the collective).
+    """Total number of snippets over all ranks (each rank may hold a different count): ONE all-reduce and one host
+    synchronisation (``.item()``), every time it is called - nothing is cached, because a rank that skipped the
+    exchange while another made it would pair that all-reduce with the wrong collective.  Call it where every rank
+    takes part (once per sharding, not per step) and pass the result as ``global_batch_size``.
     ``device``: where the exchanged scalar lives for an RCCL group - the device of the caller's tensors, not the
     process's current device."""
     import torch.distributed as dist
@@ -216,18 +219,22 @@ def global_batch(B_local: int, process_group=None, device=None) -> int:
         return B_local
     if dist.get_world_size(process_group) == 1:
         return B_local
-    key = (id(process_group) if process_group is not None else None, int(B_local))
-    gb = _global_batch_cache.get(key)
-    if gb is None:
-        backend = dist.get_backend(process_group)
-        if backend == "nccl":
-            dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-            t = torch.tensor([B_local], dtype=torch.int64, device=dev)
-        else:
-            t = torch.tensor([B_local], dtype=torch.int64)
-        dist.all_reduce(t, group=process_group)
-        gb = _global_batch_cache[key] = int(t.item())
-    return gb
+    if dist.get_backend(process_group) == "nccl":
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        t = torch.tensor([B_local], dtype=torch.int64, device=dev)
+    else:
+        t = torch.tensor([B_local], dtype=torch.int64)
+    dist.all_reduce(t, group=process_group)
+    return int(t.item())
+
+
+def _resolve_global_batch(B_local: int, global_batch_size: Optional[int], process_group) -> int:
+    if global_batch_size is not None:
+        return int(global_batch_size)
+    if _world_size(process_group) > 1:
+        raise ValueError("data parallel (more than one rank): pass global_batch_size - the number of snippets over all "
+                         "ranks, e.g. sfm_amd.loss.global_batch(B, group) evaluated once by every rank")
+    return B_local
 
 
 def allreduce_partials(partials: Tensor, process_group=None) -> Tensor:
@@ -261,19 +268,31 @@ class _FusedTotalLoss(torch.autograd.Function):
     gradients are computed with the value and scaled by the upstream scalar in ``backward``."""
 
     @staticmethod
-    def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, overlap, engine,
+    def forward(ctx, tgt, src, K, process_group, global_b, smooth_weight, explain_reg_weight, n_scales, engine,
                 fuse_resize, poses, *maps):
         S = n_scales
         pred_depth, pred_exp = list(maps[:S]), list(maps[S:2 * S])
         pred_disp = list(maps[2 * S:3 * S])
         B, H, W, _ = tgt.shape
         N = poses.shape[1]
-        need = any(ctx.needs_input_grad[11:])
+        need = any(ctx.needs_input_grad[10:])
         with torch.cuda.device(tgt.device):
             eng = engine if engine is not None else get_engine(B, H, W, S, N, tgt.device)
             if eng.dims != (B, H, W, S, N) or eng.device != tgt.device:
                 raise ValueError(f"engine was built for {eng.dims} on {eng.device}, got {(B, H, W, S, N)} on {tgt.device}")
-            fused_maps = fuse_resize and S <= MAX_PYR_SCALES and not (overlap and _world_size(process_group) > 1)
+            # The pyramid kernels take ONE size per level (the translation map's) for both of its maps; the reference
+            # resizes each map on its own (SfMLearner_uni.py:91, 113), so levels whose two maps differ in size are legal
+            # there: those go through the materialised resize.  Anything else that does not fit raises here - the
+            # kernels index with these sizes and check nothing themselves.
+            for s_, (dm, tm) in enumerate(zip(pred_depth, pred_exp)):
+                if dm.shape[0] != B or tm.shape[0] != B or dm.shape[3] != 1 or tm.shape[3] != 3 * N:
+                    raise ValueError(f"scale {s_}: pred_depth {tuple(dm.shape)} / pred_exp_logits {tuple(tm.shape)} do not "
+                                     f"match [B={B},h,w,1] / [B,h,w,3N={3 * N}]")
+                if dm.device != tgt.device or tm.device != tgt.device:
+                    raise ValueError(f"scale {s_}: pyramid maps on {dm.device} / {tm.device}, images on {tgt.device}")
+            same = all(dm.shape[1:3] == tm.shape[1:3] and tm.shape[1] <= H and tm.shape[2] <= W
+                       for dm, tm in zip(pred_depth, pred_exp))
+            fused_maps = fuse_resize and S <= MAX_PYR_SCALES and same
             if fused_maps:
                 # the kernels read the pyramid at its native sizes and resize while loading (SfMLearner_uni.py:91, 113
                 # inside the warps) and scatter the adjoint of the resize themselves: no [S,B,H,W,1+3N] intermediate
@@ -308,7 +327,7 @@ class _FusedTotalLoss(torch.autograd.Function):
                                                   out_f64=buf[eng.n_partials:] if buf is not None else None)
             try:
                 if fused_maps:
-                    eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf)
+                    eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf, process_group=process_group)
                     if side is not None:
                         torch.cuda.current_stream(tgt.device).wait_stream(side)
                         side = None
@@ -317,19 +336,13 @@ class _FusedTotalLoss(torch.autograd.Function):
                     d_into = g_smooth[S:] if g_smooth is not None else None
                     total, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf, n_elem, 1.0, need,
                                                                    d_trans_into=d_into, n_extra=buf.numel() - eng.n_partials)
-                elif overlap and _world_size(process_group) > 1:
-                    # data parallel, collectives hidden: the splat-side sums and this rank's share of the regulariser
-                    # travel in the first all-reduce (under the gather-side stencil), the min-reprojection sums in a
-                    # second one (under the backward)
-                    loss, d_depth, d_pose, d_trans, tail = eng.step_dp(tgt, src, K, depth, poses, trans, n_elem, process_group,
-                                                                       need, None if sm is None else sm.double().reshape(1))
-                    total = loss if tail is None else loss + tail[0].float()
                 else:
                     # one buffer, ONE all-reduce: the S*(3N+1) partial sums and this rank's share of the regulariser
                     buf = torch.zeros(eng.n_partials + 1, dtype=torch.float64, device=tgt.device)
                     if sm is not None:
                         buf[-1] = sm
-                    eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf[:-1])
+                    eng.forward_partials(tgt, src, K, depth, poses, trans, n_elem, need, out=buf[:-1],
+                                         process_group=process_group)
                     if global_b != B or process_group is not None:
                         allreduce_partials(buf, process_group)
                     loss, d_depth, d_pose, d_trans = eng.backward(tgt, src, K, depth, poses, trans, buf[:-1], n_elem, 1.0, need)
@@ -371,15 +384,15 @@ class _FusedTotalLoss(torch.autograd.Function):
             with torch.cuda.device(g.device):
                 n = (ctypes.c_longlong * len(grads))(*[t.numel() for t in grads])
                 call("sfm_scale_grads", P._ptrs(grads), n, len(grads), ptr(g), stream_of(g))
-            return (None,) * 11 + tuple(grads)
-        return (None,) * 11 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
+            return (None,) * 10 + tuple(grads)
+        return (None,) * 10 + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 
 def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor,
                      pred_depth: Sequence[Tensor], pred_poses: Tensor, pred_exp_logits: Sequence[Tensor],
                      pred_disp: Optional[Sequence[Tensor]] = None, smooth_weight: float = 0.0,
                      explain_reg_weight: float = 0.01, fused: bool = True, process_group=None,
-                     global_batch_size: Optional[int] = None, overlap_collectives: bool = False,
+                     global_batch_size: Optional[int] = None,
                      engine: Optional[LossEngine] = None, fuse_resize: bool = True) -> Tensor:
     """total_loss of SfMLearner_uni.py:75-176 (exp_loss is identically 0 there).
 
@@ -387,11 +400,11 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
     (``intrinsics[:,0]``, used for every scale, :125); pred_depth[s] [B,h,w,1];
     pred_poses [B,N,6]; pred_exp_logits[s] [B,h,w,3N]; pred_disp[s] for smoothness.
     ``len(pred_depth)`` scales (quirk 1).  Under data parallelism pass the process
-    group (or have torch.distributed initialised) and the loss is the global one:
-    one stream-ordered all-reduce per step, or with ``overlap_collectives`` two hidden ones
-    (``LossEngine.step_dp``: ~46 us of extra launches and stream hand-offs, so only for slow fabrics).
-    ``global_batch_size``: the number of snippets over all ranks; if omitted it is exchanged once per (group, local
-    batch) and cached (``global_batch``: one all-reduce + host sync the first time).  ``engine``: a ``LossEngine`` to
+    group (or have torch.distributed initialised) and the loss is the global one: per step one all-reduce of S*N
+    mask sums hidden under the gather-side stencil and one stream-ordered all-reduce of the partial sums.
+    ``global_batch_size``: the number of snippets over all ranks - REQUIRED when the group has more than one rank
+    (``global_batch(B, group)`` exchanges it: call it once where every rank is known to take part, not per step: a
+    per-step exchange that some ranks skip would pair with another rank's all-reduce of the sums).  ``engine``: a ``LossEngine`` to
     run on instead of the cached one of this shape, device and stream (``GraphedTotalLoss`` owns its own).
     ``fuse_resize`` (fused only): the warp kernels read ``pred_depth`` / ``pred_exp_logits`` at their native sizes and
     evaluate the ``resize_bilinear`` of :91, 113 while loading; False materialises the resized maps first
@@ -412,11 +425,11 @@ def multi_scale_loss(tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Ten
     if len(pred_exp_logits) != S:
         raise ValueError("one pred_exp_logits map per scale")
     if fused:
-        gb = global_batch_size if global_batch_size is not None else global_batch(B, process_group, tgt.device)
+        gb = _resolve_global_batch(B, global_batch_size, process_group)
         maps = list(pred_depth) + list(pred_exp_logits) + (list(pred_disp) if smooth_weight > 0 else [])
         maps = [U._check(m, "pyramid map", 4) for m in maps]
         return _FusedTotalLoss.apply(tgt, src, K, process_group, gb, float(smooth_weight), float(explain_reg_weight), S,
-                                     bool(overlap_collectives), engine, bool(fuse_resize), poses, *maps)
+                                     engine, bool(fuse_resize), poses, *maps)
     smooth = tgt.new_zeros(())
     if smooth_weight > 0:
         for s in range(S):
@@ -450,7 +463,7 @@ class GraphedTotalLoss:
     Shapes are fixed at construction.  ``__call__(raw_disp, poses, exp_logits)`` copies the network outputs into the
     graph's static inputs, replays, and returns ``(loss, d_raw_disp[s], d_poses, d_exp_logits[s])`` - views of the
     graph's static outputs, overwritten by the next call.  Single GPU or one stream-ordered all-reduce (the process
-    group's collective is captured with the kernels); not for ``overlap_collectives``."""
+    group's collectives are captured with the kernels)."""
 
     def __init__(self, tgt_image: Tensor, src_image_stack: Tensor, intrinsics: Tensor, raw_disp: Sequence[Tensor],
                  pred_poses: Tensor, pred_exp_logits: Sequence[Tensor], smooth_weight: float = 0.0,
@@ -463,7 +476,7 @@ class GraphedTotalLoss:
         self.raw = [t.detach().clone().requires_grad_(True) for t in raw_disp]
         self.exp = [t.detach().clone().requires_grad_(True) for t in pred_exp_logits]
         self.poses = pred_poses.detach().clone().requires_grad_(True)
-        gb = global_batch_size if global_batch_size is not None else global_batch(self.tgt.shape[0], process_group, dev)
+        gb = _resolve_global_batch(self.tgt.shape[0], global_batch_size, process_group)
         leaves = self.raw + self.exp + [self.poses]
         B, H, W, _ = self.tgt.shape
         # its own workspace: replays must never share Ovf / flags / params with eager calls or other graphs

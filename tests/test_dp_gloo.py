@@ -153,9 +153,9 @@ def test_summed_parameter_gradients_equal_the_single_process_gradient(tmp_path):
 
 
 class _OracleEngine(L.LossEngine):
-    """LossEngine with its four kernel calls replaced by the oracle (no GPU in this tier): what is under test is the
-    HOST sequence of step_dp - which buffer carries what through which all-reduce, and when the gather-side slots and
-    the tail are read - with uneven shards."""
+    """LossEngine with its kernel calls replaced by the oracle (no GPU in this tier): what is under test is the HOST
+    sequence of the data-parallel forward - warps -> all-reduce of the mask sums beside the gather-side stencil ->
+    splat-side stencil with the GLOBAL mask sums - with uneven shards."""
 
     def __init__(self, B_, S_, N_):
         self.dims = (B_, H, W, S_, N_)
@@ -163,36 +163,23 @@ class _OracleEngine(L.LossEngine):
         self.n_partials = S_ * (3 * N_ + 1)
         self.calls = []
 
-    def _parts(self, tgt, src, K, depth, pose, trans):
-        S_ = self.dims[3]
-        return R.loss_partials(tgt, src, K, [depth[s][..., None] for s in range(S_)], pose, [trans[s] for s in range(S_)])
-
-    def forward_splat(self, tgt, src, K, depth, pose, trans, n_elem_global, need_grad, buf):
+    def forward_warps(self, tgt, src, K, depth, pose, trans):
         S_, N_ = self.dims[3], self.dims[4]
-        self.calls.append("splat")
-        p = self._parts(tgt, src, K, depth, pose, trans).reshape(S_, 3 * N_ + 1)
-        view = buf[:self.n_partials].view(S_, 3 * N_ + 1)
-        view[:, :3 * N_] = p[:, :3 * N_]          # like sfm_loss_forward_splat: the min-reprojection slots stay untouched
+        self.calls.append("warps")
+        self._p = R.loss_partials(tgt, src, K, [depth[s][..., None] for s in range(S_)], pose,
+                                  [trans[s] for s in range(S_)]).reshape(S_, 3 * N_ + 1)
+        return self._p[:, 1:3 * N_:3].reshape(-1).clone()      # this rank's mask sums M(s, i)
 
-    def forward_gather(self, tgt, src, K, depth, pose, trans, n_elem_global, need_grad, buf, e_sums):
-        S_, N_ = self.dims[3], self.dims[4]
+    def forward_gather(self, tgt, n_elem_global, need_grad):
         self.calls.append("gather")
-        e_sums.copy_(self._parts(tgt, src, K, depth, pose, trans).reshape(S_, 3 * N_ + 1)[:, 3 * N_])
 
-    def backward(self, tgt, src, K, depth, pose, trans, partials, n_elem_global, gloss=1.0, need_grad=True):
-        self.calls.append("backward")
-        self.kv_inputs = partials[:self.n_partials].clone()    # what the gradients would be computed from
-        return torch.zeros((), dtype=torch.float32), None, None, None
-
-    def loss_value(self, buf, e_sums, n_elem_global, loss):
-        S_, N_ = self.dims[3], self.dims[4]
-        self.calls.append("value")
-        p = buf[:self.n_partials].clone().view(S_, 3 * N_ + 1)
-        p[:, 3 * N_] = e_sums
-        loss.copy_(R.loss_from_partials(p.reshape(-1), S_, N_, n_elem_global).float())
+    def forward_splat(self, src, n_elem_global, need_grad, msum_global, partials):
+        self.calls.append("splat")
+        self.msum_seen = msum_global.clone()                   # what kV0 of the seeds would be computed from
+        partials.copy_(self._p.reshape(-1))
 
 
-def _step_dp_worker(rank, world, port, out_path):
+def _dp_forward_worker(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -203,28 +190,39 @@ def _step_dp_worker(rank, world, port, out_path):
         depth = torch.stack([sl(d).squeeze(3) for d in inp["depth"]], 0)
         trans = torch.stack([sl(t) for t in inp["trans"]], 0)
         eng = _OracleEngine(hi - lo, S, N)
-        tail = torch.tensor([0.25 * (rank + 1)], dtype=torch.float64)     # this rank's share of the regulariser
-        loss, _, _, _, tail_out = eng.step_dp(sl(inp["tgt"]), sl(inp["src"]), sl(inp["K"]), depth, sl(inp["pose"]), trans,
-                                              B * H * W * 3, need_grad=False, tail=tail)
+        ne = B * H * W * 3
+        part = eng.forward_partials(sl(inp["tgt"]), sl(inp["src"]), sl(inp["K"]), depth, sl(inp["pose"]), trans, ne, True)
+        part = L.allreduce_partials(part)
+        loss = R.loss_from_partials(part, S, N, ne)
         if rank == 0:
-            torch.save({"loss": loss, "tail": tail_out.clone(), "calls": eng.calls, "kv": eng.kv_inputs}, out_path)
+            torch.save({"loss": loss, "calls": eng.calls, "msum": eng.msum_seen, "partials": part}, out_path)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(180)
-def test_overlapped_step_dp_host_sequence_with_uneven_shards(tmp_path):
-    """LossEngine.step_dp on two gloo ranks (2 + 1 snippets), the oracle standing in for the kernels: the splat-side
-    sums + tail ride in all-reduce #1, the min-reprojection sums in #2, the backward sees GLOBAL splat-side sums, and
-    the loss assembled from the two reduced buffers is the single-process loss."""
+def test_data_parallel_forward_host_sequence_with_uneven_shards(tmp_path):
+    """LossEngine.forward_partials on two gloo ranks (2 + 1 snippets), the oracle standing in for the kernels: the
+    splat-side stencil sees the mask sums of the WHOLE batch, and the loss from the reduced sums is the single-process
+    loss."""
     out_path = str(tmp_path / "sd.pt")
-    mp.spawn(_step_dp_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_dp_forward_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
     got = torch.load(out_path, weights_only=True)
     inp = synth.make_inputs(B, H, W, S=S, N=N, seed=57, pose_scale=0.03)
     ref = R.multi_scale_loss(inp["tgt"], inp["src"], inp["K"], inp["depth"], inp["pose"], inp["trans"])
-    assert got["calls"] == ["splat", "gather", "backward", "value"]
+    assert got["calls"] == ["warps", "gather", "splat"]
     assert abs(float(got["loss"]) - float(ref)) <= 2e-6 * abs(float(ref))
-    assert abs(float(got["tail"][0]) - 0.75) < 1e-12                       # 0.25 + 0.5 summed over the ranks
     whole = R.loss_partials(inp["tgt"], inp["src"], inp["K"], inp["depth"], inp["pose"], inp["trans"]).reshape(S, 3 * N + 1)
-    kv = got["kv"].reshape(S, 3 * N + 1)
-    assert torch.allclose(kv[:, :3 * N], whole[:, :3 * N], rtol=1e-9)      # global sums reached the backward
+    assert torch.allclose(got["msum"].reshape(S, N), whole[:, 1:3 * N:3], rtol=1e-9)   # global mask sums reached the seeds
+    assert torch.allclose(got["partials"].reshape(S, 3 * N + 1), whole, rtol=1e-9)
+
+
+def test_data_parallel_needs_the_global_batch_size(monkeypatch):
+    """more than one rank and no global_batch_size: rejected up front (an implicit per-step exchange that one rank skips
+    would pair with another rank's all-reduce of the sums)"""
+    monkeypatch.setattr(L, "_world_size", lambda pg=None: 2)
+    with pytest.raises(ValueError, match="global_batch_size"):
+        L._resolve_global_batch(2, None, None)
+    assert L._resolve_global_batch(2, 6, None) == 6
+    monkeypatch.setattr(L, "_world_size", lambda pg=None: 1)
+    assert L._resolve_global_batch(2, None, None) == 2

@@ -152,7 +152,7 @@ def test_sync_batch_norm_two_rehearsed_ranks_equal_the_global_batch(dev, C, spli
     for r, xs in enumerate(shards):
         xr, gr, br = xs.requires_grad_(True), gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
         mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-        y, mean, invstd = A._SyncBatchNormElu.apply(xr, gr, br, mm, mv, A.BN_DECAY, A.BN_EPSILON, True, None, stats_all)
+        y, mean, invstd = A._SyncBatchNormElu.apply(xr, gr, br, mm, mv, A.BN_DECAY, A.BN_EPSILON, True, None, stats_all, None)
         ys.append(y); leaves.append((xr, gr, br)); mms.append((mm, mv)); saved.append((mean, invstd))
     assert rel_err(torch.cat(ys), R.batch_norm_elu(x, gamma, beta)) <= 1e-5
     for mm, mv in mms:                                      # every rank holds the global moving statistics

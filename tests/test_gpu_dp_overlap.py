@@ -1,6 +1,7 @@
-"""The overlapped data-parallel step (LossEngine.step_dp: forward in two halves, two hidden all-reduces, loss from
-sfm_loss_value) against the plain sequence, on ONE GPU with a world-size-1 RCCL group: same kernels, so the results
-must be bit-identical; the collectives run through torch.distributed's nccl backend as they do at N > 1."""
+"""The data-parallel forward (LossEngine.forward_partials with more than one rank: three calls, the mask sums
+all-reduced beside the gather-side stencil) against the single-call forward, on ONE GPU with a world-size-1 RCCL group
+reported as two ranks: same kernels, so the results must be bit-identical; the collectives run through
+torch.distributed's nccl backend as they do at N > 1.  Also the synchronised batch norm over the same group."""
 import os
 
 import pytest
@@ -34,7 +35,8 @@ def _stacked(g):
 
 
 @pytest.mark.parametrize("B,H,W,S,N", [(2, 32, 64, 3, 2), (1, 37, 53, 2, 4)])
-def test_step_dp_equals_plain_step(dev, nccl_world1, B, H, W, S, N):
+def test_three_call_forward_equals_single_call(dev, nccl_world1, monkeypatch, B, H, W, S, N):
+    import sfm_amd.loss as L
     inp = synth.make_inputs(B, H, W, S=S, N=N, seed=91)
     g = synth.to_device(inp, dev)
     depth, trans = _stacked(g)
@@ -42,18 +44,22 @@ def test_step_dp_equals_plain_step(dev, nccl_world1, B, H, W, S, N):
     ne = B * H * W * 3
     p = eng.forward_partials(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, ne, True)
     ref = eng.backward(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, p, ne, 1.0, True)
-    tail = torch.tensor([0.125], dtype=torch.float64, device=dev)
+    monkeypatch.setattr(L, "_world_size", lambda pg=None: 2)
     for _ in range(2):  # twice: the workspace invariants must survive the split sequence
-        out = eng.step_dp(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, ne, None, True, tail)
-        for a, b in zip(out[:4], ref):
+        q = eng.forward_partials(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, ne, True)
+        dist.all_reduce(q)
+        out = eng.backward(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, q, ne, 1.0, True)
+        assert torch.equal(q, p)
+        for a, b in zip(out, ref):
             assert torch.equal(a, b)
-        assert float(out[4][0]) == 0.125
     torch.cuda.synchronize()
     assert eng.overflow_state() == (0, 0.0)
 
 
-def test_multi_scale_loss_takes_the_overlapped_path_and_matches_the_oracle(dev, nccl_world1, monkeypatch):
-    """with a (1-rank) group and the world size reported as 2, multi_scale_loss goes through step_dp"""
+@pytest.mark.parametrize("fuse_resize", [True, False])
+def test_multi_scale_loss_on_the_data_parallel_path_matches_the_oracle(dev, nccl_world1, monkeypatch, fuse_resize):
+    """with a (1-rank) group and the world size reported as 2, multi_scale_loss goes through the three-call forward
+    (pyramid and materialised resize)"""
     import sfm_amd.loss as L
     monkeypatch.setattr(L, "_world_size", lambda pg=None: 2)
     inp = synth.make_inputs(2, 32, 64, S=3, N=2, seed=92, full_res=False)
@@ -66,13 +72,16 @@ def test_multi_scale_loss_takes_the_overlapped_path_and_matches_the_oracle(dev, 
     dg = [d.requires_grad_(True) for d in g["depth"]]
     tg = [t.requires_grad_(True) for t in g["trans"]]
     pg = g["pose"].requires_grad_(True)
+    with pytest.raises(ValueError, match="global_batch_size"):
+        sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], dg, pg, tg, pred_disp=g["disp"], smooth_weight=0.01)
     lg = sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], dg, pg, tg, pred_disp=g["disp"], smooth_weight=0.01,
-                                  global_batch_size=2, overlap_collectives=True)
+                                  global_batch_size=2, fuse_resize=fuse_resize)
     lg.backward()
     assert rel_err(lg, lo) <= TOL_OUT
     assert rel_err(pg.grad, po.grad) <= TOL_GRAD
     for s in range(3):
         assert rel_err(tg[s].grad, to[s].grad) <= TOL_GRAD
+        assert rel_err(dg[s].grad, do[s].grad) <= TOL_GRAD
 
 
 def test_sync_batch_norm_over_a_one_rank_rccl_group_equals_plain_batch_norm(dev, nccl_world1):

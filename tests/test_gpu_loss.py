@@ -122,3 +122,84 @@ def test_overflow_path_and_workspace_invariant(dev):
     eng = sfm_amd.loss.get_engine(B, H, W, S, N, dev)
     torch.cuda.synchronize()
     assert eng.overflow_state() == (0, 0.0), "Ovf / flags not restored to zero after the steps"
+
+
+def _stacked_dev(inp, dev):
+    g = synth.to_device(inp, dev)
+    depth = torch.stack([d.squeeze(3) for d in g["depth"]], 0).contiguous()
+    trans = torch.stack(g["trans"], 0).contiguous()
+    return g, depth, trans
+
+
+@pytest.mark.parametrize("B,H,W,S,N,ps", [(2, 32, 64, 2, 2, 0.01), (1, 96, 200, 2, 2, 0.15), (1, 37, 53, 2, 4, 0.3),
+                                          (1, 128, 416, 2, 2, 0.1)])
+def test_mask_sums_taken_before_the_stencil_equal_the_stencils_own(dev, B, H, W, S, N, ps):
+    """kV0 of the combined seed plane uses M(s, i) = sum_q nz(q) wgt(q), counted where the splat tiles are written and
+    corrected for the pixels that received overflow contributions (large poses: most tiles do); the stencil's own
+    sum of m = avgpool3x3(nz) over the finished accumulators (partials[..., 1]) must agree, and so must the oracle's."""
+    from sfm_amd.loss import LossEngine
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=71, pose_scale=ps)
+    g, depth, trans = _stacked_dev(inp, dev)
+    eng = LossEngine(B, H, W, S, N, dev)
+    ne = B * H * W * 3
+    for _ in range(2):
+        p = eng.forward_partials(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, ne, True)
+        torch.cuda.synchronize()
+        n_flagged, _ = eng.overflow_state()
+        early = eng.region("msum").view(torch.float64).clone()
+        eng.backward(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, p, ne, 1.0, True)
+        late = p.view(S, 3 * N + 1)[:, 1:3 * N:3].reshape(-1)
+        assert rel_err(early, late) <= 1e-6, f"{n_flagged} tiles with overflow"
+    if ps >= 0.1:
+        assert n_flagged > 0, "the case was meant to exercise the overflow fix-up"
+    ref = R.loss_partials(inp["tgt"], inp["src"], inp["K"], inp["depth"], inp["pose"], inp["trans"]).view(S, 3 * N + 1)
+    assert rel_err(early.cpu(), ref[:, 1:3 * N:3].reshape(-1)) <= 1e-5
+
+
+def test_seed_guard_rewrites_the_seeds_when_the_clip_does_not_pass(dev):
+    """clip((1 - mean ssim) / 2, 0, 1) (utils.py:575) has no gradient outside [0, 1].  The seeds are written before the
+    global mean SSIM exists, assuming it passes; when the reduced sums say otherwise the backward first rewrites the
+    seeds of that (scale, source) with kV0 = 0.  Forced here by handing the backward sums with mean SSIM = 1.5 for some
+    pairs; reference = autograd of the oracle's loss_from_partials on the same sums."""
+    from sfm_amd.loss import LossEngine
+    B, H, W, S, N = 2, 32, 64, 2, 2
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=72, pose_scale=0.02)
+    g, depth, trans = _stacked_dev(inp, dev)
+    eng = LossEngine(B, H, W, S, N, dev)
+    ne = B * H * W * 3
+    for failing in ([(0, 1)], [(0, 0), (1, 0), (1, 1)], []):
+        p = eng.forward_partials(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, ne, True)
+        for s, i in failing:
+            p.view(S, 3 * N + 1)[s, 3 * i + 2] = 1.5 * ne
+        loss, d_depth, d_pose, d_trans = eng.backward(g["tgt"], g["src"], g["K"], depth, g["pose"], trans, p, ne, 1.0, True)
+        do = [d.clone().requires_grad_(True) for d in inp["depth"]]
+        to = [t.clone().requires_grad_(True) for t in inp["trans"]]
+        po = inp["pose"].clone().requires_grad_(True)
+        part = R.loss_partials(inp["tgt"], inp["src"], inp["K"], do, po, to)
+        fake = part.detach().clone().view(S, 3 * N + 1)
+        for s, i in failing:
+            fake[s, 3 * i + 2] = 1.5 * ne
+        lo = R.loss_from_partials(part + (fake.reshape(-1) - part.detach()), S, N, ne)
+        lo.backward()
+        assert rel_err(loss, lo.float()) <= TOL_OUT
+        assert rel_err(d_pose, po.grad) <= TOL_GRAD, failing
+        for s in range(S):
+            assert rel_err(d_depth[s], do[s].grad.squeeze(3)) <= TOL_GRAD, failing
+            assert rel_err(d_trans[s], to[s].grad) <= TOL_GRAD, failing
+
+
+def test_mismatched_pyramid_maps_are_rejected_or_resized_separately(dev):
+    """the pyramid kernels index both maps of a level with ONE size: a depth map sized unlike its translation map
+    (legal in the reference, which resizes each on its own) must take the materialised resize; wrong batch / channel
+    counts must raise before anything is launched"""
+    B, H, W, S, N = 2, 32, 64, 2, 2
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=73, full_res=False)
+    odd = [inp["depth"][0], torch.nn.functional.interpolate(inp["depth"][1].permute(0, 3, 1, 2), size=(12, 20)).permute(0, 2, 3, 1).contiguous()]
+    lo = R.multi_scale_loss(inp["tgt"], inp["src"], inp["K"], odd, inp["pose"], inp["trans"])
+    g = synth.to_device(inp, dev)
+    lg = sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], [d.to(dev) for d in odd], g["pose"], g["trans"])
+    assert rel_err(lg, lo) <= TOL_OUT
+    with pytest.raises(ValueError, match="do not match"):
+        sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], [g["depth"][0][:1], g["depth"][1]], g["pose"], g["trans"])
+    with pytest.raises(ValueError, match="do not match"):
+        sfm_amd.multi_scale_loss(g["tgt"], g["src"], g["K"], g["depth"], g["pose"], [g["trans"][0][..., :3], g["trans"][1]])

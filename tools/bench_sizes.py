@@ -34,12 +34,12 @@ for label, B, H, W, S, N, city in CASES:
     print(f"   overflow flags raised: {nf} of {S * N * B} images", flush=True)
     import ctypes
     from sfm_amd import _lib
-    lib = _lib.load(); st = (ctypes.c_float * 7)()
+    lib = _lib.load(); st = (ctypes.c_float * lib.sfm_prof_stages())()
     lib.sfm_prof_enable(1)
     for _ in range(3):
         step(); torch.cuda.synchronize(); lib.sfm_prof_read(st)
     lib.sfm_prof_enable(0)
-    names = ["tile_shift", "warp_fwd", "stencil", "reduce", "finalize", "warp_bwd", "pose_grad"]
+    names = ["tile_shift", "warp_fwd", "stencil", "reduce", "seed_guard", "warp_bwd", "pose_grad", "mask_sums"]
     print("   stage us per Mpix-scale:", {n: round(v / 3 * 1e3 / (B * H * W * S / 1e6), 1) for n, v in zip(names, st)}, flush=True)
     print(f"{label}: {dt*1e3:.3f} ms/step  {units/dt/1e9:.2f} Gpix/s  step_frac_of_hbm_peak {130.0*units/dt/8e12:.3f}  "
           f"workspace {eng.ws.numel()*4/2**30:.2f} GiB  loss {float(out[0]):.5f}", flush=True)

@@ -24,7 +24,7 @@ print("shift x", tab[:,0].min().item(), tab[:,0].max().item(), "y", tab[:,1].min
 print("reach x hist", sorted(collections.Counter(tab[:,2].tolist()).items()))
 print("reach y hist", sorted(collections.Counter(tab[:,3].tolist()).items()))
 print("redundancy", ((64+2*tab[:,2]).float()*(32+2*tab[:,3]).float()).mean().item()/2048)
-lib=_lib.load(); st=(ctypes.c_float*7)()
+lib=_lib.load(); st=(ctypes.c_float*lib.sfm_prof_stages())()
 eng.backward(tgt, src, K, depth, pose, trans, p, NE, 1.0, True)
 lib.sfm_prof_enable(1)
 for _ in range(3):
