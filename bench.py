@@ -26,6 +26,8 @@ The JSON line also carries
   config1         configs[0]: one projective_warp -> bilinear_project forward at B=1, GPU and CPU side by side;
   strong_scaling  configs[2] (1248x384, B=32 over N GPUs) and configs[3] (2048x1024 seq=5, B=64 over N GPUs)
                   with the global batch fixed: the same fused step on B/N snippets per rank;
+  config5         configs[4] as one chained step: decoder of disp_aspp_u_dense -> normalize_disp -> multi_scale_loss ->
+                  backward through loss and decoder;
   slices          1-GPU runs of the per-GPU slices (c3 B=16, c4 B=8) and the 10x pose stress variant of c2, with
                   the share of splat tiles that took the overflow path.
 """
@@ -224,6 +226,78 @@ def aspp_leg(dev, reps: int = 5) -> dict:
     return {"workload": "11 dilated 3x3 convs of disp_aspp_u_dense, B=8 416x128, fwd + bwd-data + bwd-weight (configs[4])",
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
             "ms": ms, "flops": flops, "dtype": "f32"}
+
+
+def decoder_flops(b: int, h: int, w: int) -> float:
+    """2*M*K*N of every convolution of disp_aspp_u_dense's decoder (stem, five levels, three heads), forward only"""
+    from sfm_amd.aspp import DECODER_LEVELS
+    fl = 2.0 * b * h * w * 2048 * 1024
+    hh, ww = h, w
+    for name, ci, co, skip, skip2 in DECODER_LEVELS:
+        hh, ww = 2 * hh, 2 * ww
+        m = b * hh * ww
+        parts = 4 + (skip2 is not None)
+        fl += 2.0 * m * (ci * ci + ci * co + 9 * ci * co + 9 * 2 * co * co + parts * co * co)
+        fl += 2.0 * m * (skip[1] * co if skip is not None else 9 * 2 * co * co)
+        if skip2 is not None:
+            fl += 2.0 * m * skip2 * co
+        if name in ("concat2", "concat3", "concat4"):
+            fl += 2.0 * m * 9 * co
+    return fl
+
+
+def config5_leg(dev, reps: int = 10) -> dict:
+    """configs[4] as ONE step: the decoder of disp_aspp_u_dense on synthetic ResNet end-points (nets.py:666-692: stem,
+    five disp_bottleneck_dense levels, three heads) -> disp / mean(disp), 1 / disp (SfMLearner_uni.py:40, 47) ->
+    multi_scale_loss over the decoder's three maps -> backward through loss and decoder down to every decoder weight
+    and end-point.  Random-init weights, B=8, 416x128; wall clock around the whole chain, host dispatch included."""
+    import torch
+    import sfm_amd
+    from sfm_amd import aspp as A
+    from sfm_amd import synth
+    s3 = 3  # the decoder returns three disparities (nets.py:692; num_scales = 3 in SfMLearner_x.py:261, quirk 1 of SURVEY.md)
+    params = A.make_decoder_params(dev, 5)
+    leaves = []
+    for q in params.values():      # 'stem' / heads: name -> tensor; levels: name -> dict of name -> tensor
+        for v in q.values():
+            leaves += [t.requires_grad_(True) for t in (v.values() if isinstance(v, dict) else [v])]
+    ends = {k: v.requires_grad_(True) for k, v in A.make_end_points(B, H // 32, W // 32, dev, 5).items()}
+    inp = synth.to_device(synth.make_inputs(B, H, W, S=s3, N=N, seed=synth.SEED, full_res=False), dev)
+    trans = [t.requires_grad_(True) for t in inp["trans"]]
+    pose = inp["pose"].requires_grad_(True)
+    every = leaves + list(ends.values()) + trans + [pose]
+
+    def step(with_loss=True):
+        for t in every:
+            t.grad = None
+        disp = sfm_amd.disp_aspp_u_dense_decoder(ends, params)
+        if with_loss:
+            dn, dp = sfm_amd.normalize_disp(disp)
+            loss = sfm_amd.multi_scale_loss(inp["tgt"], inp["src"], inp["K"], dp, pose, trans, pred_disp=dn, smooth_weight=0.01)
+        else:  # the decoder alone under a linear functional of its outputs (what the loss adds is the difference)
+            loss = sum(d.sum() for d in disp)
+        loss.backward()
+        return loss
+
+    def timed(with_loss):
+        for _ in range(3):
+            step(with_loss)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = step(with_loss)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+
+    ms_dec, _ = timed(False)
+    ms, loss = timed(True)
+    fl = 3.0 * decoder_flops(B, H // 32, W // 32)  # forward + backward-data + backward-weight
+    return {"workload": f"disp_aspp_u_dense decoder (stem + 5 levels + 3 heads, random-init, synthetic ResNet end-points) -> "
+                        f"normalize_disp -> multi_scale_loss (S={s3}: the decoder's three maps, N={N}, smooth_weight=0.01) -> "
+                        f"backward through loss and decoder, B={B} {W}x{H} (configs[4]); host dispatch included",
+            "ms_per_step": ms, "ms_decoder_fwd_bwd_alone": ms_dec, "loss": float(loss.detach()),
+            "decoder_conv_flops_fwd_bwd": fl, "decoder_TFLOPs_at_alone_time": fl / (ms_dec * 1e-3) / 1e12,
+            "pixel_warps_per_step": B * H * W * s3 * N * 2, "Gpix_per_s": B * H * W * s3 * N * 2 / (ms * 1e-3) / 1e9}
 
 
 def total_loss_leg(dev, reps: int = 50) -> dict:
@@ -671,7 +745,11 @@ def main() -> None:
             line["strong_scaling"] = strong
         if extras:
             line["aspp"] = aspp_leg(dev)
-            line["config"]["config5_step_ms"] = ms_step + line["aspp"]["ms"]  # ASPP convs + warp loss, fwd + bwd
+            try:
+                line["config5"] = config5_leg(dev)
+                line["config"]["config5_step_ms"] = line["config5"]["ms_per_step"]  # ONE chained step, measured
+            except Exception as e:  # a failed extra leg must not take the headline line with it
+                line["config5"] = {"error": f"{type(e).__name__}: {e}"}
             line["end_to_end"] = total_loss_leg(dev)
             line["loader"] = loader_leg(dev)
             line["slices"] = slices_leg(dev)

@@ -292,11 +292,24 @@ int sfm_aspp_conv1x1_bwd_data(const float* gout, const float* w, int B, int H, i
 int sfm_aspp_conv1x1_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, float* gw,
                                 float* ws, void* stream);
 
+/* ---- the disparity heads of disp_aspp_u_dense (nets.py:678, 683, 689) ---------------------------------------
+ * disp = DISP_SCALING * slim.conv2d(x, 1, [3, 3], activation_fn=tf.sigmoid, normalizer_fn=None) + MIN_DISP with
+ * DISP_SCALING = 10, MIN_DISP = 0.01 (nets.py:11-12): x [B,H,W,Cin] NHWC, w [3,3,Cin,1] HWIO, bias [1] (no normaliser,
+ * so slim adds a bias), SAME padding -> disp [B,H,W,1]; sig [B,H,W] receives the sigmoid for the backward.  Cin / 4
+ * must be a power of two <= 64.  Backward (TF autodiff): gdisp = dL/d disp -> gx [B,H,W,Cin] (may be NULL), gw
+ * [3,3,Cin,1] and gb [1] (both or neither); ws: sfm_disp_head_workspace_floats() floats of workgroup partials,
+ * summed in a fixed order (reproducible). */
+long long sfm_disp_head_workspace_floats(int B, int H, int W, int Cin);
+int sfm_disp_head_fwd(const float* x, const float* w, const float* bias, int B, int H, int W, int Cin, float* disp,
+                      float* sig, void* stream);
+int sfm_disp_head_bwd(const float* x, const float* w, const float* sig, const float* gdisp, int B, int H, int W, int Cin,
+                      float* gx, float* gw, float* gb, float* ws, void* stream);
+
 /* ---- batch norm + ELU after each ASPP convolution -----------------------------------
  * What the arg-scope of disp_aspp_u_dense (nets.py:653-656 -> resnet/resnet_utils.py:232-251) appends to every
  * slim.conv2d of disp_bottleneck_dense (nets.py:455-470): slim.batch_norm(decay, epsilon, scale=True, fused=True,
  * is_training=True, updates_collections=None) then tf.nn.elu.  x [M, C] = the convolution's output (M = B*H*W rows,
- * NHWC; C a multiple of 4, at most 1024), gamma / beta [C].  Training mode: batch statistics (population
+ * NHWC; C a multiple of 4), gamma / beta [C].  Training mode: batch statistics (population
  * variance), saved in save_mean / save_invstd [C] for the backward; moving_mean / moving_var [C] (may be NULL) are
  * updated in place as assign_moving_average does: m -= (m - batch) * fp32(1 - decay), the variance with Bessel's
  * correction (fused_batch_norm).  Reductions in a fixed order.

@@ -575,6 +575,37 @@ def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Optional[Tens
     return sc(torch.cat(parts, dim=3), "out", activation=False), upnet
 
 
+DISP_SCALING = 10    # nets.py:11
+MIN_DISP = 0.01      # nets.py:12
+
+
+def disp_head(x_nhwc: Tensor, w_hwio: Tensor, bias: Tensor) -> Tensor:
+    """``DISP_SCALING * slim.conv2d(x, 1, [3, 3], activation_fn=tf.sigmoid, normalizer_fn=None) + MIN_DISP``
+    (nets.py:678, 683, 689): no normaliser, so slim.conv2d adds its bias (zeros-initialised variable); SAME padding."""
+    y = F.conv2d(x_nhwc.permute(0, 3, 1, 2).contiguous(), w_hwio.permute(3, 2, 0, 1).contiguous(), bias=bias,
+                 padding=1).permute(0, 2, 3, 1)
+    return DISP_SCALING * torch.sigmoid(y) + MIN_DISP
+
+
+def disp_aspp_u_dense_decoder(end_points: dict, params: dict):
+    """nets.py:666-692 after the ResNet: batch norm + ELU + 1x1 (no activation) on block4 (:672-673), five
+    ``disp_bottleneck_dense`` levels (:675-686), three heads (:678, 683, 689).  Returns [disp4, disp3, disp2].
+    ``end_points`` / ``params`` as in sfm_amd.aspp.disp_aspp_u_dense_decoder."""
+    q = params["stem_bn"]
+    upnet = batch_norm_elu(end_points["block4"], q["gamma"], q["beta"])
+    q = params["stem"]
+    upnet = batch_norm_elu(conv1x1(upnet, q["w"]), q["gamma"], q["beta"], activation=False)
+    concat, _ = disp_bottleneck_dense(params["concat"], upnet, end_points["block3"], use_skip2=False)
+    concat1, skip1 = disp_bottleneck_dense(params["concat1"], concat, end_points["block2"], use_skip2=False)
+    xconcat2, skip2 = disp_bottleneck_dense(params["concat2"], concat1, end_points["block1"], skip2=skip1)
+    disp2 = disp_head(xconcat2, params["disp2"]["w"], params["disp2"]["b"])
+    xconcat3, skip3 = disp_bottleneck_dense(params["concat3"], xconcat2, end_points["root_block"], rates=(3, 6), skip2=skip2)
+    disp3 = disp_head(xconcat3, params["disp3"]["w"], params["disp3"]["b"])
+    xconcat4, _ = disp_bottleneck_dense(params["concat4"], xconcat3, None, rates=(3, 6), use_skip=False, skip2=skip3)
+    disp4 = disp_head(xconcat4, params["disp4"]["w"], params["disp4"]["b"])
+    return [disp4, disp3, disp2]
+
+
 # ----------------------------------------------------------------------------
 # data-parallel decomposition of the pixel loss (SURVEY.md section 8e)
 # ----------------------------------------------------------------------------

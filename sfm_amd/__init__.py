@@ -18,7 +18,7 @@ from .utils import (bilinear_project, bilinear_sampler, cam2pixel, corner_indice
 from .loss import GraphedTotalLoss, multi_scale_loss  # noqa: F401
 from .pyramid import compute_smooth_loss, normalize_disp, resize_bilinear  # noqa: F401
 from .aspp import (GradBuckets, allreduce_weight_grads, batch_norm_elu, conv1x1, conv2d_bn_elu, dilated_conv3x3,  # noqa: F401
-                   disp_bottleneck_dense)
+                   disp_aspp_u_dense_decoder, disp_bottleneck_dense, disp_head)
 from .data_loader import AugmentDraws, DataLoader, snippet_unpack  # noqa: F401
 from . import synth  # noqa: F401
 from ._lib import SfmAmdError  # noqa: F401
@@ -26,6 +26,6 @@ from ._lib import SfmAmdError  # noqa: F401
 __all__ = ["projective_inverse_warp", "projective_warp", "bilinear_sampler", "bilinear_project", "tf_ssim",
            "ssim_value", "pose_vec2mat", "euler2mat", "meshgrid", "pixel2cam", "cam2pixel", "project_coords",
            "corner_indices", "multi_scale_loss", "GraphedTotalLoss", "compute_smooth_loss", "resize_bilinear", "normalize_disp",
-           "dilated_conv3x3", "batch_norm_elu", "conv2d_bn_elu", "conv1x1", "disp_bottleneck_dense", "allreduce_weight_grads", "GradBuckets",
+           "dilated_conv3x3", "batch_norm_elu", "conv2d_bn_elu", "conv1x1", "disp_bottleneck_dense", "disp_head", "disp_aspp_u_dense_decoder", "allreduce_weight_grads", "GradBuckets",
            "DataLoader", "AugmentDraws", "snippet_unpack",
            "SfmAmdError"]

@@ -75,6 +75,9 @@ SIGNATURES = {
     "sfm_aspp_conv1x1_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv1x1_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv1x1_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_disp_head_workspace_floats": [_I, _I, _I, _I],
+    "sfm_disp_head_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_disp_head_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sfm_bn_elu_workspace_floats": [_LL, _I],
     "sfm_bn_elu_fwd": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P, _P],
     "sfm_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P],

@@ -125,7 +125,7 @@ class _BatchNormElu(torch.autograd.Function):
         lib = _lib.load()
         n_ws = lib.sfm_bn_elu_workspace_floats(M, C)
         if n_ws < 0:
-            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4, at most 1024)")
+            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4)")
         with torch.cuda.device(x.device):
             ws = torch.empty(n_ws // 2 + 1, dtype=torch.float64, device=x.device)  # fp64 partials: 8-byte aligned
             y = torch.empty_like(x)
@@ -167,7 +167,7 @@ class _SyncBatchNormElu(torch.autograd.Function):
         lib = _lib.load()
         n_ws = lib.sfm_bn_elu_workspace_floats(M, C)
         if n_ws < 0:
-            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4, at most 1024)")
+            raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4)")
         with torch.cuda.device(x.device):
             ws = torch.empty(n_ws // 2 + 1, dtype=torch.float64, device=x.device)
             if stats_override is None:
@@ -358,6 +358,133 @@ def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None
         parts.append(conv(s2, params, "skip2"))                                    # :466
     xconcat = conv(torch.cat(parts, dim=3), params, "out", activation=False)       # :470
     return xconcat, upnet
+
+
+DISP_SCALING = 10    # nets.py:11
+MIN_DISP = 0.01      # nets.py:12
+
+
+class _DispHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, H, W, Cin = x.shape
+        with torch.cuda.device(x.device):
+            disp = torch.empty(B, H, W, 1, dtype=torch.float32, device=x.device)
+            sig = torch.empty(B, H, W, dtype=torch.float32, device=x.device)
+            call("sfm_disp_head_fwd", ptr(x), ptr(w), ptr(b), B, H, W, Cin, ptr(disp), ptr(sig), stream_of(x))
+        ctx.save_for_backward(x, w, sig)
+        ctx.b_ref = b if _sink_of(b) is not None else None
+        return disp
+
+    @staticmethod
+    def backward(ctx, gdisp):
+        x, w, sig = ctx.saved_tensors
+        B, H, W, Cin = x.shape
+        gdisp = gdisp.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gx = gw = gb = ws = None
+        with torch.cuda.device(x.device):
+            if need_x:
+                gx = torch.empty_like(x)
+            if need_w:
+                gw = _grad_out(w)
+                gb = _grad_out(ctx.b_ref) if ctx.b_ref is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+                ws = torch.empty(_lib.load().sfm_disp_head_workspace_floats(B, H, W, Cin), dtype=torch.float32, device=x.device)
+            call("sfm_disp_head_bwd", ptr(x), ptr(w), ptr(sig), ptr(gdisp), B, H, W, Cin, ptr(gx), ptr(gw), ptr(gb), ptr(ws),
+                 stream_of(x))
+        return gx, gw, gb
+
+
+def disp_head(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """``DISP_SCALING * slim.conv2d(x, 1, [3, 3], activation_fn=tf.sigmoid, normalizer_fn=None) + MIN_DISP`` - the
+    disparity heads of ``disp_aspp_u_dense`` (nets.py:678, 683, 689): x [B,H,W,Cin], w [3,3,Cin,1] (HWIO), b [1] ->
+    [B,H,W,1].  Cin / 4 must be a power of two <= 64."""
+    x = _check(x, "x", 4)
+    Cin = x.shape[3]
+    w = _check(w, "w", 4)
+    b = _check(b, "b", 1, 1)
+    if tuple(w.shape) != (3, 3, Cin, 1):
+        raise ValueError(f"w must be [3, 3, {Cin}, 1], got {tuple(w.shape)}")
+    if Cin % 4 or (Cin // 4) & (Cin // 4 - 1) or Cin > 256:
+        raise ValueError(f"Cin / 4 must be a power of two <= 64, got Cin = {Cin}")
+    _same_device(x, w, b)
+    return _DispHead.apply(x, w, b)
+
+
+def disp_aspp_u_dense_decoder(end_points: dict, params: dict, process_group=None):
+    """The decoder of ``nets.disp_aspp_u_dense`` (nets.py:666-692) from the ResNet end-points to the three disparity
+    maps - everything of the network that is not the stock ResNet-v2-50 encoder: batch norm + ELU + 1x1 on block4
+    (:672-673), the five ``disp_bottleneck_dense`` levels (:675-686) and the three heads (:678, 683, 689).
+
+    ``end_points``: 'block4' [B,h,w,2048], 'block3' [B,2h,2w,1024], 'block2' [B,4h,4w,512], 'block1' [B,8h,8w,256],
+    'root_block' [B,16h,16w,64] (``resnet_v2_50_mod`` at output_stride 32, resnet/resnet_v2.py:287-306; h x w = 4 x 13
+    for a 128 x 416 image).  ``params``: 'stem_bn' = dict(gamma, beta[, moving_mean, moving_var]) (:672), 'stem' =
+    dict(w [1,1,2048,1024], gamma, beta, ...) (:673), 'concat', 'concat1', 'concat2', 'concat3', 'concat4' = the
+    parameter dicts of ``disp_bottleneck_dense``, 'disp2', 'disp3', 'disp4' = dict(w [3,3,C,1], b [1]).
+    Returns ``[disp4, disp3, disp2]`` like the reference ([B,32h,32w,1], [B,16h,16w,1], [B,8h,8w,1])."""
+    q = params["stem_bn"]
+    upnet = batch_norm_elu(end_points["block4"], q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"),
+                           process_group=process_group)                                                      # :672
+    upnet = _slim_conv(upnet, params, "stem", activation=False, process_group=process_group)                 # :673
+    lvl = lambda name, x, skip, **kw: disp_bottleneck_dense(params[name], x, skip, process_group=process_group, **kw)  # noqa: E731
+    concat, _ = lvl("concat", upnet, end_points["block3"], use_skip2=False)                                  # :675
+    concat1, skip1 = lvl("concat1", concat, end_points["block2"], use_skip2=False)                           # :676
+    xconcat2, skip2 = lvl("concat2", concat1, end_points["block1"], skip2=skip1)                             # :677
+    disp2 = disp_head(xconcat2, params["disp2"]["w"], params["disp2"]["b"])                                  # :678
+    xconcat3, skip3 = lvl("concat3", xconcat2, end_points["root_block"], rates=(3, 6), skip2=skip2)          # :681
+    disp3 = disp_head(xconcat3, params["disp3"]["w"], params["disp3"]["b"])                                  # :683
+    xconcat4, _ = lvl("concat4", xconcat3, None, rates=(3, 6), use_skip=False, skip2=skip3)                  # :686
+    disp4 = disp_head(xconcat4, params["disp4"]["w"], params["disp4"]["b"])                                  # :689
+    return [disp4, disp3, disp2]
+
+
+DECODER_LEVELS = (  # name, Cin, Cout, skip end-point (channels) or None, channels of skip2 or None
+    ("concat", 1024, 512, ("block3", 1024), None), ("concat1", 512, 256, ("block2", 512), None),
+    ("concat2", 256, 128, ("block1", 256), 512), ("concat3", 128, 64, ("root_block", 64), 256),
+    ("concat4", 64, 32, None, 128))
+
+
+def make_decoder_params(device, seed: int = 0, width_div: int = 1) -> dict:
+    """Random-init parameters of ``disp_aspp_u_dense_decoder`` in the layout it reads (He-style weights, gamma ~ 1,
+    beta ~ 0; moving statistics omitted).  ``width_div``: every channel count divided by it (small test decoders)."""
+    g = torch.Generator().manual_seed(seed)
+    dv = lambda c: max(32, c // width_div)  # noqa: E731
+
+    def vec(c, scale, shift):
+        return (torch.randn(c, generator=g) * scale + shift).to(device)
+
+    def conv(k, ci, co):
+        return dict(w=(torch.randn(k, k, ci, co, generator=g) / (k * ci ** 0.5)).to(device), gamma=vec(co, 0.1, 1.0),
+                    beta=vec(co, 0.1, 0.0))
+
+    p = {"stem_bn": dict(gamma=vec(dv(2048), 0.1, 1.0), beta=vec(dv(2048), 0.1, 0.0)), "stem": conv(1, dv(2048), dv(1024))}
+    for name, ci, co, skip, skip2 in DECODER_LEVELS:
+        ci, co = dv(ci), dv(co)
+        q = dict(up=conv(1, ci, ci), sup=conv(1, ci, co), aspp_up=conv(3, ci, co), aspp_up2=conv(3, 2 * co, co))
+        n_parts = 4
+        if skip is not None:
+            q["skip_bn"] = dict(gamma=vec(dv(skip[1]), 0.1, 1.0), beta=vec(dv(skip[1]), 0.1, 0.0))
+            q["skip"] = conv(1, dv(skip[1]), co)
+        else:
+            q["skip"] = conv(3, 2 * co, co)
+        if skip2 is not None:
+            q["skip2"] = conv(1, dv(skip2), co)
+            n_parts = 5
+        q["out"] = conv(1, n_parts * co, co)
+        p[name] = q
+    for name, c in (("disp2", 128), ("disp3", 64), ("disp4", 32)):
+        c = dv(c)
+        p[name] = dict(w=(torch.randn(3, 3, c, 1, generator=g) / (3 * c ** 0.5)).to(device), b=vec(1, 0.1, 0.0))
+    return p
+
+
+def make_end_points(B: int, h: int, w: int, device, seed: int = 0, width_div: int = 1) -> dict:
+    """Synthetic ResNet end-points of the shapes ``resnet_v2_50_mod`` produces for a 32h x 32w image."""
+    g = torch.Generator().manual_seed(seed + 1)
+    dv = lambda c: max(32, c // width_div)  # noqa: E731
+    shapes = {"block4": (h, w, 2048), "block3": (2 * h, 2 * w, 1024), "block2": (4 * h, 4 * w, 512),
+              "block1": (8 * h, 8 * w, 256), "root_block": (16 * h, 16 * w, 64)}
+    return {k: torch.randn(B, hh, ww, dv(c), generator=g).to(device) for k, (hh, ww, c) in shapes.items()}
 
 
 # ----------------------------------------------------------------------------- data parallel (SURVEY.md 8e, config 5)

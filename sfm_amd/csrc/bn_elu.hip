@@ -25,16 +25,19 @@ namespace {
 
 struct BnPlan {
   int groups;      // C / 4 channel groups of a row
-  int row_lanes;   // kBlock / groups: rows a workgroup reads per iteration
+  int gslab;       // channel groups one workgroup covers (<= kBlock); wider rows are cut into slabs along grid.y
+  int slabs;
+  int row_lanes;   // kBlock / gslab: rows a workgroup reads per iteration
   long rows_per_chunk;
   int chunks;
 };
 
 static inline bool bn_plan(long M, int C, BnPlan& p) {
-  if (M < 1 || C < 4 || C % 4) return false;
+  if (M < 1 || C < 4 || C % 4 || C > 65536) return false;
   p.groups = C / 4;
-  if (p.groups > kBlock) return false;
-  p.row_lanes = kBlock / p.groups;  // threads beyond groups * row_lanes idle (C / 4 need not divide 256)
+  p.gslab = p.groups < kBlock ? p.groups : kBlock;
+  p.slabs = (p.groups + p.gslab - 1) / p.gslab;
+  p.row_lanes = kBlock / p.gslab;  // threads beyond gslab * row_lanes idle (C / 4 need not divide 256)
   long chunks = (M + p.row_lanes - 1) / p.row_lanes;  // at least one iteration each
   if (chunks > 512) chunks = 512;
   p.rows_per_chunk = ((M + chunks - 1) / chunks + p.row_lanes - 1) / p.row_lanes * p.row_lanes;
@@ -53,7 +56,9 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restr
                                                             const float* __restrict__ invstd, long M, int C, BnPlan p,
                                                             int act, double* __restrict__ part) {
   __shared__ double red[kBlock][8];
-  const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
+  const int gl = threadIdx.x % p.gslab, rl = threadIdx.x / p.gslab;
+  const int g = min((int)blockIdx.y * p.gslab + gl, p.groups - 1);  // (the tail of the last slab repeats its last group)
+  const bool mine = (int)blockIdx.y * p.gslab + gl < p.groups;
   const long r0 = (long)blockIdx.x * p.rows_per_chunk, r1 = min(M, r0 + p.rows_per_chunk);
   double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = s4, i4 = s4;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restr
     m4 = *reinterpret_cast<const float4*>(mean + 4 * g);
     i4 = *reinterpret_cast<const float4*>(invstd + 4 * g);
   }
-  for (long r = rl < p.row_lanes ? r0 + rl : r1; r < r1; r += p.row_lanes) {
+  for (long r = (rl < p.row_lanes && mine) ? r0 + rl : r1; r < r1; r += p.row_lanes) {
     const size_t o = (size_t)r * C + 4 * g;
     const float4 xv = *reinterpret_cast<const float4*>(x + o);
     if (MODE == 0) {
@@ -81,11 +86,11 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = a[k]; red[threadIdx.x][4 + k] = b[k]; }
   __syncthreads();
-  if (rl == 0) {
+  if (rl == 0 && mine) {
     double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
     for (int j = 0; j < p.row_lanes; ++j)  // fixed order
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { sa[k] += red[j * p.groups + g][k]; sb[k] += red[j * p.groups + g][4 + k]; }
+      for (int k = 0; k < 4; ++k) { sa[k] += red[j * p.gslab + gl][k]; sb[k] += red[j * p.gslab + gl][4 + k]; }
     double* o = part + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { o[4 * g + k] = sa[k]; o[C + 4 * g + k] = sb[k]; }
@@ -252,7 +257,7 @@ extern "C" int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* b
   if (((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;  // fp64 partials
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks), dim3(kBlock), 0, stream, x, (const float*)nullptr,
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, x, (long)M, C,
                      p.chunks, eps, (float)(1.0 - decay), moving_mean, moving_var, save_mean, save_invstd);
@@ -271,7 +276,7 @@ extern "C" int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, c
   if (((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
                      p, act, part);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma,
                      gbeta);
@@ -291,7 +296,7 @@ extern "C" int sfm_bn_local_stats(const float* x, long long M, int C, double* st
   if (!x || !stats || !ws || !bn_plan((long)M, C, p) || ((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks), dim3(kBlock), 0, stream, x, (const float*)nullptr,
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
   hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, x, (long)M, C, p.chunks, stats);
   return sfm_last_error();
@@ -324,7 +329,7 @@ extern "C" int sfm_bn_elu_bwd_sums(const float* x, const float* y, const float* 
     return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
                      p, act, part);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma, gbeta);
   return sfm_last_error();

@@ -585,7 +585,7 @@ template <int NL, bool GATHERED, int NTC, int IB, bool PYR>
 #define SFM_WPE_BWD
 #endif
 #ifndef SFM_BWD_PAIR
-#define SFM_BWD_PAIR 1  // sources whose gathers are in flight together (1: 143 VGPRs = three waves per SIMD; 2: 190)
+#define SFM_BWD_PAIR 2  // sources whose gathers are in flight together (with one seed plane and one pixel per thread both fit: 84 VGPRs)
 #endif
 __global__ __launch_bounds__(kBlock) SFM_WPE_BWD
 void loss_warp_bwd_kernel(const float* __restrict__ tgt,

@@ -109,7 +109,8 @@ constexpr int STW = 64, STH = SFM_STH;  // splat: destination tile of one workgr
 #endif
 constexpr int kSplatThreads = STW * STH / SFM_SPLAT_PPT;  // home pixels per thread
 #ifndef SFM_BTH
-#define SFM_BTH 8  // 64x8: 3328 workgroups at c2 - finer than 64x16 against the 768 resident ones (quantisation: -9 %)
+#define SFM_BTH 4  // 64x4 = one pixel per thread: no loop-carried prefetch state, 84 VGPRs = five waves per SIMD with both
+                   // sources' gathers in flight (SFM_BWD_PAIR 2): 54 -> 50 us at c2 against 64x8 tiles at 132 VGPRs
 #endif
 constexpr int BTW = 64, BTH = SFM_BTH;  // backward warp: pixel tile of one workgroup
 constexpr int kLossPPT = BTW * BTH / kBlock;  // pixels per thread in the backward warp kernel
