@@ -158,16 +158,26 @@ __global__ __launch_bounds__(kBlock) void disp_head_bwd_weight_kernel(const floa
   }
 }
 
-// gw[k] = sum over the workgroups' partials in workgroup order (fp64 running sum); k == 9 Cin: the bias gradient
+// gw[k] = sum of the workgroups' partials (fp64; fixed order: four interleaved row classes, then those in order);
+// k == 9 Cin: the bias gradient.  A workgroup owns 64 adjacent outputs (coalesced rows), its four waves a row class each.
 __global__ __launch_bounds__(kBlock) void disp_head_bwd_reduce_kernel(const float* __restrict__ partials, int n_rows, int Cin,
                                                                       float* __restrict__ gw, float* __restrict__ gb) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k > 9 * Cin) return;
+  __shared__ double red[kBlock];
+  const int k = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
   const int stride = 9 * Cin + 4;
+  const bool ok = k <= 9 * Cin;
   double s = 0.0;
-  for (int r = 0; r < n_rows; ++r) s += (double)partials[(size_t)r * stride + k];
-  if (k < 9 * Cin) gw[k] = (float)s;
-  else gb[0] = (float)s;
+  if (ok) {
+#pragma unroll 8
+    for (int r = rq; r < n_rows; r += kBlock / 64) s += (double)partials[(size_t)r * stride + k];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rq == 0 && ok) {
+    const double t = ((red[threadIdx.x] + red[64 + threadIdx.x]) + red[128 + threadIdx.x]) + red[192 + threadIdx.x];
+    if (k < 9 * Cin) gw[k] = (float)t;
+    else gb[0] = (float)t;
+  }
 }
 
 bool head_dims(int B, int H, int W, int Cin, HeadDims& d) {
@@ -216,7 +226,7 @@ extern "C" int sfm_disp_head_bwd(const float* x, const float* w, const float* si
   if (gw) {
     const unsigned nb = head_grid(d, kHeadBlocks);
     hipLaunchKernelGGL(disp_head_bwd_weight_kernel, dim3(nb), dim3(kBlock), 0, stream, x, sig, gdisp, d, ws);
-    hipLaunchKernelGGL(disp_head_bwd_reduce_kernel, dim3((9 * Cin + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, ws, (int)nb,
+    hipLaunchKernelGGL(disp_head_bwd_reduce_kernel, dim3((9 * Cin + 1 + 63) / 64), dim3(kBlock), 0, stream, ws, (int)nb,
                        Cin, gw, gb);
   }
   return sfm_last_error();
