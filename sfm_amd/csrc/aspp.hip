@@ -11,14 +11,18 @@
 //                                                                                              transposed weights (Cin <-> Cout)
 //   backward weight  gw[tap, ci, co] = sum_p in[p + off(tap), ci] * gout[p, co]                M = Cin, N = Cout, K = B*H*W per tap
 //
-// One tile core for all three: a workgroup owns a BM x BN output tile, waves own WM x WN sub-tiles
-// made of 32x32 MFMA tiles; per K-step of 32 the A tile is staged in LDS K-major ([k][m], so the
-// MFMA operand read "lane l -> A[m = l & 31][k = l >> 5]" is a conflict-free ds_read_b32) and the B
-// tile as [k][n]; the next step's global loads are issued into registers before the MFMAs of the
-// current one.  The im2col matrix never exists: a tap is a shifted (zero-padded) view of the input.
-// Small-M / small-output problems split K over workgroups (taps for the forward, pixel ranges for
-// the weight gradient) into partial slabs that a second kernel sums in a fixed order: results are
-// bitwise reproducible, no atomics.
+// Forward and backward-data (aspp_conv_sk_kernel) and the weight gradient of the >= 128-channel levels
+// (aspp_wgrad_sk_kernel) share one design: a workgroup owns BM x BN output tiles (128x128, 256x64, 256x32), waves own
+// WM x WN sub-tiles made of 32x32 MFMA tiles; K advances in steps of 32.  Tiles are staged by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers) into two buffers with ONE barrier per K-step, by dedicated LOADER
+// waves, while the MULTIPLIER waves only read LDS and issue MFMAs (a DMA issued beside a busy matrix pipe stalls for
+// hundreds of cycles, so the two jobs do not share a wave).  The im2col matrix never exists: a tap is a shifted
+// (zero-padded) view of the input.  Work is dealt stream-K: the tiles x K-steps units of a layer are cut into ONE
+// contiguous range per workgroup, 2 workgroups per CU; a range that ends inside a tile leaves a partial slab and
+// aspp_sk_fixup_kernel adds a tile's slabs in workgroup order - bitwise reproducible, no atomics.  The 64 -> 32
+// level's weight gradient keeps its own kernel (aspp_wgrad9_kernel: all nine taps of a 64x32 block per workgroup on a
+// shared input patch, register staging; one tap per workgroup is L2-bound there at 10 flop/byte), smaller odd shapes
+// the plain split-K kernel (aspp_wgrad_kernel).  Measured MFMA-pipe utilisation: profiles/r03_aspp_pmc.txt.
 #include "sfm_device.h"
 #include "sfm_internal.h"
 #include <algorithm>
