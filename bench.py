@@ -394,7 +394,7 @@ def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scal
     a = (inp["tgt"], inp["src"], inp["K"], inp["depth"], inp["pose"], inp["trans"])
 
     def step():
-        p = eng.forward_partials(*a, ne, True, msum_allreduce=MSUM_ALLREDUCE)
+        p = eng.forward_partials(*a, ne, True)
         if world > 1:
             allreduce_(p)
         return eng.backward(*a, p, ne, 1.0, True)
@@ -443,9 +443,6 @@ def slices_leg(dev) -> dict:
     return out
 
 
-MSUM_ALLREDUCE = None  # set in main() for the rehearsal backend: the mask sums staged through host memory as well
-
-
 def allreduce_(t, op=None):
     """dist.all_reduce in place.  RCCL reduces the device tensor itself; the rehearsal backend (SFM_BENCH_BACKEND=gloo,
     several ranks on one GPU) stages through host memory - gloo's own device path hangs with two ranks on one ROCm
@@ -467,10 +464,9 @@ def collective_backend() -> str:
     return "RCCL" if b == "nccl" else f"{b} (rehearsal: staged through host memory)"
 
 
-def strong_scaling_legs(dev, world, rank) -> dict:
-    """configs[2] / configs[3]: the global batch fixed, B/world snippets per rank, one all-reduce per step."""
-    import torch
-    import torch.distributed as dist
+def strong_plan(world: int) -> dict:
+    """What the strong-scaling legs will run at this world size (host arithmetic only: also printed by the CPU rehearsal):
+    key -> {"workload", "n_gpus", "per_gpu_batch", "need_GiB"} or {"workload", "skipped"}."""
     out = {}
     for key, c in STRONG.items():
         label = c["label"]
@@ -483,6 +479,22 @@ def strong_scaling_legs(dev, world, rank) -> dict:
             out[key] = {"workload": label, "skipped": f"B={b} per GPU needs {need:.0f} GiB of workspace + tensors (> "
                                                       f"{MEM_BUDGET_GIB:.0f} GiB budget of one 288 GB GPU)"}
             continue
+        out[key] = {"workload": label, "scaling": "strong", "n_gpus": world, "per_gpu_batch": b, "need_GiB": need}
+    return out
+
+
+def strong_scaling_legs(dev, world, rank) -> dict:
+    """configs[2] / configs[3]: the global batch fixed, B/world snippets per rank, two small all-reduces per step."""
+    import torch
+    import torch.distributed as dist
+    out = {}
+    plan = strong_plan(world)
+    for key, c in STRONG.items():
+        label = c["label"]
+        if "skipped" in plan[key]:
+            out[key] = plan[key]
+            continue
+        b = plan[key]["per_gpu_batch"]
         steps, warm = (10, 3) if key == "c3" else (4, 2)
         try:
             r = fused_step_leg(dev, b, c["H"], c["W"], c["S"], c["N"], c["city"], world, rank, steps, warm)
@@ -561,9 +573,12 @@ def rehearse(args) -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     buf = torch.full((S * (3 * N + 1),), float(rank + 1), dtype=torch.float64)
+    msum = torch.full((S * N,), float(rank + 1), dtype=torch.float64)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if world > 1:
+        if world > 1:  # the step's two collectives, in its order: mask sums (asynchronous), then the partial sums
+            work = dist.all_reduce(msum, async_op=True)
+            work.wait()
             dist.all_reduce(buf)
     if world > 1:
         dist.barrier()
@@ -572,7 +587,8 @@ def rehearse(args) -> None:
         allreduce_(t, dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps({"metric": "launcher rehearsal (no kernels)", "value": None, "unit": "Gpix/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "seconds": float(t.item())}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "seconds": float(t.item()),
+                          "strong_scaling": strong_plan(world)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -652,14 +668,10 @@ def main() -> None:
     eng = LossEngine(B, H, W, S, N, dev)
     n_elem_global = world * B * H * W * 3
 
-    global MSUM_ALLREDUCE
-    if (world > 1 or force_dp) and backend != "nccl":
-        MSUM_ALLREDUCE = lambda t: allreduce_(t) and None  # noqa: E731  (synchronous, through host memory)
     dp = world > 1 or force_dp
 
     def step():
-        partials = eng.forward_partials(tgt, src, K, depth, pose, trans, n_elem_global, True, dp=dp,
-                                        msum_allreduce=MSUM_ALLREDUCE)
+        partials = eng.forward_partials(tgt, src, K, depth, pose, trans, n_elem_global, True, dp=dp)
         if dp:
             allreduce_(partials)
         return eng.backward(tgt, src, K, depth, pose, trans, partials, n_elem_global, 1.0, True)

@@ -98,7 +98,7 @@ class LossEngine:
             if msum_allreduce is not None:
                 work = msum_allreduce(msum)
             else:
-                work = dist.all_reduce(msum, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+                work = _all_reduce_sum(msum, process_group, async_op=True)
             self.forward_gather(tgt, n_elem_global, need_grad)
             if work is not None:
                 work.wait()  # device tensors: the current stream waits for the collective, not the host
@@ -242,8 +242,22 @@ def allreduce_partials(partials: Tensor, process_group=None) -> Tensor:
     tensors; gloo in the CPU tests)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
-        dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=process_group)
+        _all_reduce_sum(partials, process_group)
     return partials
+
+
+def _all_reduce_sum(t: Tensor, process_group=None, async_op: bool = False):
+    """Sum ``t`` over the ranks in place.  RCCL (backend "nccl") reduces the device tensor itself, asynchronously if
+    asked (returns the work handle); any other backend with a device tensor - gloo rehearsals of the multi-rank path on
+    one GPU - stages through host memory, synchronously (returns None)."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(process_group) != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=process_group)
+        t.copy_(h)
+        return None
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op)
+    return work if async_op else None
 
 
 _SIDE_STREAM = os.environ.get("SFM_LOSS_SIDE_STREAM", "1") != "0"

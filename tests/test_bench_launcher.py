@@ -34,6 +34,10 @@ def test_bench_spawns_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3 and lines[0]["rehearsal"] is True
+    # the strong-scaling plan of the line: configs[2] (B=32) and configs[3] (B=64) halved over the two ranks
+    ss = lines[0]["strong_scaling"]
+    assert ss["c3"]["n_gpus"] == 2 and ss["c3"]["per_gpu_batch"] == 16
+    assert ss["c4"]["n_gpus"] == 2 and ss["c4"]["per_gpu_batch"] == 32
 
 
 @pytest.mark.timeout(300)
@@ -55,3 +59,27 @@ def test_single_rank_rehearsal_needs_no_process_group():
                        capture_output=True, text=True, env=_env(), timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _json_lines(r.stdout)[0]["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_run_the_whole_data_parallel_sequence(dev):
+    """The N = 2 sequence end to end on the one GPU of the test box: launcher, two ranks sharing the device, the
+    three-call forward with the mask-sum all-reduce, the partial-sum all-reduce, the strong-scaling legs - collectives
+    staged through host memory (SFM_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device).  What RCCL itself does
+    at N > 1 is the one thing this cannot show."""
+    env = _env()
+    env.update(SFM_BENCH_BACKEND="gloo", SFM_BENCH_WATCHDOG="500")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    assert "gloo" in line["config"]["collectives"] and "mask sums" in line["config"]["collectives"]
+    ss = line["strong_scaling"]
+    assert ss["c3"]["n_gpus"] == 2 and ss["c3"]["per_gpu_batch"] == 16 and ss["c3"]["ms_per_step"] > 0
+    assert ss["c4"]["n_gpus"] == 2 and ss["c4"]["per_gpu_batch"] == 32
+    assert "ms_per_step" in ss["c4"] or "skipped" in ss["c4"] or "error" in ss["c4"]
+    assert 0.0 < line["config"]["loss"] < 100.0
