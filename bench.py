@@ -367,7 +367,8 @@ class LegSetupError(RuntimeError):
     """a leg could not be set up (allocation) on some rank; every rank knows and skips the leg"""
 
 
-def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scale=0.01, with_flags=False) -> dict:
+def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scale=0.01, with_flags=False,
+                   relative_field=False) -> dict:
     """The fused step on `b` snippets of this rank (inputs generated on the device); under world > 1 with the
     stream-ordered all-reduce of the partial sums and the global denominators.  Returns this rank's timing (the caller
     takes the max over ranks)."""
@@ -379,7 +380,8 @@ def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scal
     # not allocate must not leave the others waiting in the step's all-reduces
     err = None
     try:
-        inp = synth.make_step_inputs_device(b, h, w, s, n, synth.SEED + 101 * rank, dev, pose_scale=pose_scale, cityscapes=city)
+        inp = synth.make_step_inputs_device(b, h, w, s, n, synth.SEED + 101 * rank, dev, pose_scale=pose_scale, cityscapes=city,
+                                            relative_field=relative_field)
         eng = LossEngine(b, h, w, s, n, dev)
     except Exception as e:
         err = f"{type(e).__name__}: {e}"
@@ -428,12 +430,16 @@ def fused_step_leg(dev, b, h, w, s, n, city, world, rank, steps, warm, pose_scal
 def slices_leg(dev) -> dict:
     out = {}
     cases = [("c3_B16", "1248x384 B=16 (configs[2] over 2 GPUs) S=4 N=2", 16, 384, 1248, 4, 2, False, 0.01, 10, 3),
-             ("c4_B8", "2048x1024 Cityscapes intrinsics B=8 (configs[3] over 8 GPUs) S=4 N=4", 8, 1024, 2048, 4, 4, True, 0.01, 5, 2),
+             ("c4_B8", "2048x1024 Cityscapes intrinsics B=8 (configs[3] over 8 GPUs) S=4 N=4; depth noise on an H/8 x W/8 grid: "
+              "the parallax changes completely every 8 px (harsher than a smooth field)", 8, 1024, 2048, 4, 4, True, 0.01, 5, 2),
+             ("c4_B8_relative_field", "the same with the depth / translation noise on the 16 x 52 grid of the 416x128 "
+              "configuration (the same scene content at the higher resolution)", 8, 1024, 2048, 4, 4, True, 0.01, 5, 2),
              ("c2_pose_x10", f"{W}x{H} B={B} S={S} N={N}, 10x pose scale (SURVEY.md 8d stress variant: out-of-bounds, contention)",
               B, H, W, S, N, False, 0.1, 50, 10)]
     for key, label, b, h, w, s, n, city, ps, steps, warm in cases:
         try:
-            r = fused_step_leg(dev, b, h, w, s, n, city, 1, 0, steps, warm, pose_scale=ps, with_flags=True)
+            r = fused_step_leg(dev, b, h, w, s, n, city, 1, 0, steps, warm, pose_scale=ps, with_flags=True,
+                               relative_field=key.endswith("relative_field"))
             units = b * h * w * s * n * 2
             out[key] = {"workload": label, "ms_per_step": r["dt"] * 1e3, "Gpix_per_s": units / r["dt"] / 1e9,
                         "step_frac_of_hbm_peak": STEP_BYTES_PER_PAIR / 2 * units / r["dt"] / 1e9 / HBM_PEAK_GBS,

@@ -66,17 +66,21 @@ def to_device(inp: Dict[str, object], device) -> Dict[str, object]:
 
 
 def make_step_inputs_device(B: int, H: int, W: int, S: int, N: int, seed: int, device, pose_scale: float = 0.01,
-                            cityscapes: bool = False) -> Dict[str, torch.Tensor]:
+                            cityscapes: bool = False, relative_field: bool = False) -> Dict[str, torch.Tensor]:
     """The tensors one fused step reads, generated ON the device (same distributions as ``make_inputs`` with
     ``full_res=True``, a device generator - not bit-identical to the CPU stream): for the large benchmark
     configurations, where CPU generation and the host -> device copy of tens of GB would dominate the run.
     Returns tgt [B,H,W,3], src [B,H,W,3N], K [B,3,3], pose [B,N,6], depth [S,B,H,W], trans [S,B,H,W,3N] (stacked,
-    the layout sfm_loss_forward reads)."""
+    the layout sfm_loss_forward reads).  ``relative_field``: the depth / translation noise lives on the 16 x 52 grid
+    the 128 x 416 configuration has (one cell = 1/52 of the image width at every resolution) instead of one cell per
+    8 pixels - the same scene content at a higher resolution, rather than 4x finer depth detail."""
     dev = torch.device(device)
     g = torch.Generator(device=dev).manual_seed(seed)
 
     def smooth(b, c, k):
         h, w = max(H // k, 2), max(W // k, 2)
+        if relative_field and k == 8:
+            h, w = 16, 52
         z = torch.rand(b, c, h, w, generator=g, device=dev) * 2 - 1
         z = F.interpolate(z, size=(H, W), mode="bilinear", align_corners=True)
         return z.permute(0, 2, 3, 1)
