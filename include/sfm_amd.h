@@ -158,7 +158,15 @@ int sfm_ssim_bwd(const float* img1, const float* img2, const float* gv, int B, i
  *   sfm_loss_forward_gather  the gather-side stencil (min-reprojection term)
  *   sfm_loss_forward_splat   the splat-side stencil with the GLOBAL mask sums, then partials[S*(3N+1)]
  *   [all-reduce (sum) of partials]  ->  sfm_loss_backward
- * (_gather before _splat; all on one stream or ordered by events.) */
+ * (_gather before _splat; all on one stream or ordered by events.)
+ *
+ * The seed guard.  The seeds are written assuming clip((1 - mean ssim) / 2, 0, 1) (utils.py:575) passes its gradient,
+ * which it does unless the global mean SSIM of a (scale, source) leaves [-1, 1] (degenerate inputs); for that case
+ * the seeds of that pair are rewritten without the SSIM part once the sums are global.  sfm_loss_forward does this in
+ * its own reduction (single device: its sums ARE the global ones); sfm_loss_backward does it for the three-call
+ * forward, from the all-reduced partials.  need_grad of sfm_loss_backward: 0 = loss only, 1 = gradients (the guard is
+ * applied first), 3 = gradients and `partials` are exactly what sfm_loss_forward wrote for this workspace (guard
+ * already applied: one launch less). */
 long long sfm_loss_workspace_floats(int B, int H, int W, int S, int N);
 int sfm_loss_num_partials(int B, int H, int W, int S, int N);
 int sfm_loss_workspace_init(float* ws, int B, int H, int W, int S, int N, void* stream);

@@ -435,37 +435,16 @@ __global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_t
   }
 }
 
-// The mask-sum share of a tile that received overflow contributions: its Acc alone was not the final accumulator when
-// the tile's owner counted the non-zero pixels.  One wave per (image, tile); exits at once unless the tile's counter is
-// raised, else walks the listed pixels (each once) and adds [nz(Acc + Ovf) - nz(Acc)] * wgt to the tile's share.
+// the mask-sum fix-up as a launch of its own (data-parallel forward; the single-device forward runs it inside the
+// gather-side stencil launch): one wave per (image, tile), msum_fix_tile in loss_common.h
 __global__ __launch_bounds__(kBlock) void loss_msum_fix_kernel(const float* __restrict__ Acc, const float* __restrict__ Ovf,
                                                               const int* __restrict__ flags,
                                                               const unsigned short* __restrict__ ovl,
                                                               float* __restrict__ msumt, int H, int W, int tiles_x,
                                                               int ntile, long n_tiles_all) {
-  constexpr int TP = STW * STH;
   const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (w >= n_tiles_all) return;
-  const int cnt = min(flags[w], TP);
-  if (cnt == 0) return;
-  const int lane = threadIdx.x & 63;
-  const long img = w / ntile;
-  const int tile = (int)(w - img * ntile);
-  const int x0 = (tile % tiles_x) * STW, y0 = (tile / tiles_x) * STH;
-  const float4* __restrict__ a = reinterpret_cast<const float4*>(Acc) + (size_t)img * H * W;
-  const float4* __restrict__ o = reinterpret_cast<const float4*>(Ovf) + (size_t)img * H * W;
-  float dsum = 0.0f;
-  for (int e = lane; e < cnt; e += 64) {
-    const int l = ovl[(size_t)w * TP + e];
-    const int u = x0 + (l & (STW - 1)), v = y0 + l / STW;
-    const size_t p = (size_t)v * W + u;
-    const float4 av = a[p], ov = o[p];
-    const float before = nz_count(av.x, av.y, av.z, av.w);
-    const float after = nz_count(av.x + ov.x, av.y + ov.y, av.z + ov.z, av.w + ov.w);  // the stencil's Acc + Ovf
-    dsum += (after - before) * (mask_axis_weight(u, W) * mask_axis_weight(v, H));
-  }
-  dsum = wave_sum_dpp_lane63(dsum);
-  if (lane == 63) msumt[w] += dsum;
+  msum_fix_tile(w, threadIdx.x & 63, Acc, Ovf, flags, ovl, msumt, H, W, tiles_x, ntile);
 }
 
 // msumt -> msum[S*N] (fp64; the addends are fp32 values of one magnitude, so the fp64 sum is exact whatever the order).
@@ -495,43 +474,6 @@ __global__ __launch_bounds__(kBlock) void loss_ovf_clear_kernel(float* __restric
   for (int k = threadIdx.x; k < STW * STH; k += kBlock) {
     const int u = x0 + (k & (STW - 1)), v = y0 + k / STW;
     if (u < W && v < H) o[(size_t)v * W + u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-
-// ------------------------------------------------------------------ reduce
-// per-wave partial sums of the stencil kernel -> partials fp64 [S][3N+1], fixed summation order
-// (deterministic).  grid (S, 3N+1): block (s, t) owns one term.
-// t0: first term of the launch (grid.y terms from there); e_out (may be null): where the min-reprojection sum of a
-// scale goes instead of partials[s][3N] (the overlapped data-parallel step reduces the two sides separately).
-__global__ __launch_bounds__(kBlock) void loss_reduce_kernel(const float* __restrict__ wavep, LossDims d, StencilPlan p,
-                                                             double* __restrict__ partials, int t0,
-                                                             double* __restrict__ e_out) {
-  __shared__ double red[kBlock];
-  const int s = blockIdx.x, t = t0 + blockIdx.y;
-  const int nterm = 3 * d.N + 1;
-  long per = (long)d.B * p.per_img;  // waves per (scale, source) image set
-  long first;
-  int comp;
-  if (t < 3 * d.N) {
-    first = ((long)s * d.N + t / 3) * per;
-    comp = t % 3;
-  } else {
-    per = (long)d.B * p.per_img_g;
-    first = p.n_splat + (long)s * per;
-    comp = 0;
-  }
-  double acc = 0.0;
-  if (t < 3 * d.N || p.n_gather > 0)
-    for (long k = threadIdx.x; k < per; k += kBlock) acc += (double)wavep[(first + k) * kWaveTerms + comp];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int o = kBlock / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    if (t == 3 * d.N && e_out) e_out[s] = red[0];
-    else partials[(size_t)s * nterm + t] = red[0];
   }
 }
 
@@ -1011,6 +953,7 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
   float* msumt = ws + w.msumt;
   unsigned short* ovl = reinterpret_cast<unsigned short*>(ws + w.ovl);
   double* msum_ws = reinterpret_cast<double*>(ws + w.msum);
+  const bool single = phases == kPhaseAll && !msum_out && !msum_in;
   int rc;
   if (phases & kPhaseWarps) {
     { StageTimer t(ST_SHIFT, stream);
@@ -1032,7 +975,9 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
       hipLaunchKernelGGL(loss_splat_tile_kernel<false>, grid, dim3(kSplatThreads), 0, stream, tgt, src, depth, trans, pmv, params, d,
                          sfm_lin_step(W), sfm_lin_step(H), w.stiles_x, w.stiles_y, shift, ws + w.G, ws + w.Acc, ws + w.Ovf, flags,
                          msumt, ovl); }
-    { StageTimer t(ST_MSUM, stream);
+    // single device (every phase in this call, the mask sums never leave the workspace): no launch here - the fix-up rides
+    // in the gather-side stencil launch and the splat-side waves add up the tile shares themselves
+    if (!single) { StageTimer t(ST_MSUM, stream);
     const int ntile = w.stiles_x * w.stiles_y;
     hipLaunchKernelGGL(loss_msum_fix_kernel, dim3((unsigned)((w.n_flags + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
                        stream, ws + w.Acc, ws + w.Ovf, flags, ovl, msumt, H, W, w.stiles_x, ntile, w.n_flags);
@@ -1044,15 +989,16 @@ static int loss_forward_phases(int phases, const float* tgt, const float* src, c
   if (!(phases & (kPhaseGather | kPhaseSplat))) return SFM_OK;
   StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, w.stiles_x, w.stiles_y, ws + w.Hb, ws + w.dG, ws + w.wavep, d, l.sp,
                 (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global),
-                msum_in ? msum_in : msum_ws, 1.0 / (double)n_elem_global};
+                single ? (const double*)nullptr : (msum_in ? msum_in : msum_ws), 1.0 / (double)n_elem_global, msumt, ovl,
+                single ? (int)((w.n_flags + kBlock / 64 - 1) / (kBlock / 64)) : 0};
   { StageTimer t(ST_STENCIL, stream);
   rc = launch_loss_stencil(a, need_grad != 0, ((phases & kPhaseGather) ? kStencilGather : 0) | ((phases & kPhaseSplat) ? kStencilSplat : 0),
                            stream);
   if (rc) return rc; }
   if (phases & kPhaseSplat) {
     StageTimer t(ST_REDUCE, stream);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(S, 3 * N + 1), dim3(kBlock), 0, stream, ws + w.wavep, d, l.sp, partials, 0,
-                       (double*)nullptr);
+    rc = launch_loss_reduce(a, partials, single && need_grad != 0, stream);
+    if (rc) return rc;
   }
   return sfm_last_error();
 }
@@ -1119,11 +1065,12 @@ static int loss_backward_common(const float* tgt, const float* src, const float*
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)w.n_flags * sizeof(int), stream);
     return e != hipSuccess ? (int)e : sfm_last_error();
   }
-  { // seeds written under a clip that turned out not to pass (degenerate inputs only): rewritten before they are read
+  if (!(need_grad & 2)) {  // (need_grad = 3: sfm_loss_forward's own reduction has applied the guard - single device)
+    // seeds written under a clip that turned out not to pass (degenerate inputs only): rewritten before they are read
     StageTimer t(ST_FINALIZE, stream);
     StencilArgs a{tgt, src, ws + w.G, ws + w.Acc, ws + w.Ovf, flags, w.stiles_x, w.stiles_y, ws + w.Hb, ws + w.dG, ws + w.wavep, d, ll.sp,
                   (float)((double)kAlpha / (double)n_elem_global), (float)(2.0 / (double)n_elem_global),
-                  reinterpret_cast<const double*>(ws + w.msum), 1.0 / (double)n_elem_global};
+                  reinterpret_cast<const double*>(ws + w.msum), 1.0 / (double)n_elem_global, nullptr, nullptr, 0};
     const int rc0 = launch_loss_stencil_redo(a, partials, stream);
     if (rc0) return rc0;
   }

@@ -168,8 +168,13 @@ struct StencilArgs {
   StencilPlan p;
   float kL1;  // alpha / n_elem_global          (coefficient of the masked L1 term, :149)
   float kE;   // 2 / n_elem_global              (coefficient of the min-reprojection term, :168)
-  const double* msum;  // [S*N] GLOBAL mask sums M(s, i) = sum m (all ranks), known before the splat-side stencil runs
+  const double* msum;  // [S*N] GLOBAL mask sums M(s, i) = sum m (all ranks), known before the splat-side stencil runs;
+                       // null (single device): every splat-side wave adds up the tile shares of its (scale, source) itself
   double inv_n;        // 1 / n_elem_global
+  float* msumt;        // [n_img][tiles] the tile shares (loss_splat_tile_kernel; corrected by msum_fix_tile)
+  const unsigned short* ovl;  // the listed overflow pixels per tile
+  int fix_blocks;      // > 0 (single device): the gather-side launch carries that many extra workgroups, which run the
+                       // mask-sum fix-up of the tiles (msum_fix_tile) beside the gather-side strips - one launch less
 };
 
 // Coefficient of the SSIM part of the splat-side seeds: d/dSp of (1 - alpha) mean(m) clip((1 - mean ssim) / 2, 0, 1)
@@ -200,11 +205,43 @@ __device__ __forceinline__ float nz_count(float r, float g, float b, float w) {
   return ((r * inv == 0.0f) ? 0.0f : 1.0f) + ((g * inv == 0.0f) ? 0.0f : 1.0f) + ((b * inv == 0.0f) ? 0.0f : 1.0f);
 }
 
+// The mask-sum share of a tile that received overflow contributions: its Acc alone was not the final accumulator when
+// the tile's owner counted the non-zero pixels.  One wave per (image, tile) w; returns at once unless the tile's counter
+// is raised, else walks the listed pixels (each once) and adds [nz(Acc + Ovf) - nz(Acc)] * wgt to the tile's share.
+__device__ __forceinline__ void msum_fix_tile(long w, int lane, const float* __restrict__ Acc, const float* __restrict__ Ovf,
+                                              const int* __restrict__ flags, const unsigned short* __restrict__ ovl,
+                                              float* __restrict__ msumt, int H, int W, int tiles_x, int ntile) {
+  constexpr int TP = STW * STH;
+  const int cnt = min(flags[w], TP);
+  if (cnt == 0) return;
+  const long img = w / ntile;
+  const int tile = (int)(w - img * ntile);
+  const int x0 = (tile % tiles_x) * STW, y0 = (tile / tiles_x) * STH;
+  const float4* __restrict__ a = reinterpret_cast<const float4*>(Acc) + (size_t)img * H * W;
+  const float4* __restrict__ o = reinterpret_cast<const float4*>(Ovf) + (size_t)img * H * W;
+  float dsum = 0.0f;
+  for (int e = lane; e < cnt; e += 64) {
+    const int l = ovl[(size_t)w * TP + e];
+    const int u = x0 + (l & (STW - 1)), v = y0 + l / STW;
+    const size_t p = (size_t)v * W + u;
+    const float4 av = a[p], ov = o[p];
+    const float before = nz_count(av.x, av.y, av.z, av.w);
+    const float after = nz_count(av.x + ov.x, av.y + ov.y, av.z + ov.z, av.w + ov.w);  // the stencil's Acc + Ovf
+    dsum += (after - before) * (mask_axis_weight(u, W) * mask_axis_weight(v, H));
+  }
+  dsum = wave_sum_dpp_lane63(dsum);
+  if (lane == 63) msumt[w] += dsum;
+}
+
 // loss_stencil.hip.  which: the gather side (min-reprojection term), the splat side (masked L1 + SSIM terms), or both
 constexpr int kStencilGather = 1, kStencilSplat = 2;
 int launch_loss_stencil(const StencilArgs& a, bool need_grad, int which, hipStream_t stream);
 // rewrites the seeds of every (scale, source) whose clip does not pass (global sums in partials) with kV0 = 0; exits at
 // once otherwise (the normal case)
 int launch_loss_stencil_redo(const StencilArgs& a, const double* partials, hipStream_t stream);
+// per-wave partial sums of the stencil kernels -> partials fp64 [S][3N+1], fixed summation order (deterministic).
+// guard (single device: the sums are already global): the workgroup that has just formed V(s, i) applies the seed guard
+// to that (scale, source) itself, so the backward needs no guard launch.
+int launch_loss_reduce(const StencilArgs& a, double* partials, bool guard, hipStream_t stream);
 
 }  // namespace sfm

@@ -307,7 +307,7 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   const int b = it.img % d.B, s_ = it.img / d.B;
   it.img = (s_ * d.N + i) * d.B + b;
   if constexpr (REDO) {
-    if (loss_clip_passes(partials[s_ * (3 * d.N + 1) + 3 * i + 2], a.inv_n)) return;  // wave-uniform
+    if (partials && loss_clip_passes(partials[s_ * (3 * d.N + 1) + 3 * i + 2], a.inv_n)) return;  // wave-uniform
   }
   wavep_out += ((size_t)it.img * a.p.per_img + (size_t)it.chunk * a.p.strips + it.strip) * kWaveTerms;
   const int lane = threadIdx.x & 63;
@@ -332,7 +332,23 @@ __device__ __forceinline__ void splat_item(const StencilArgs& a, long item, floa
   w.ovf = any_ovf ? a.Ovf + (size_t)it.img * HW * 4 : nullptr;
   w.sp = a.src + (size_t)b * HW * w.C3 + 3 * i;
   w.hb = a.Hb + (size_t)it.img * HW * 4;
-  w.kV0 = (GRAD && !REDO) ? loss_kv0(a.msum[s_ * d.N + i], a.inv_n) : 0.0f;
+  w.kV0 = 0.0f;
+  if constexpr (GRAD && !REDO) {
+    double M;
+    if (a.msum) {
+      M = a.msum[s_ * d.N + i];
+    } else {
+      // single device: the tile shares of this (scale, source) - B * tiles consecutive floats - added up here, by every
+      // wave in the same order (the fp64 sum of these fp32 values is exact anyway: loss_msum_reduce_kernel)
+      const int per = d.B * a.stiles_x * a.stiles_y;
+      const float* __restrict__ mt = a.msumt + (size_t)(s_ * d.N + i) * per;
+      M = 0.0;
+      for (int k = lane; k < per; k += 64) M += (double)mt[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) M += __shfl_xor(M, o, 64);
+    }
+    w.kV0 = loss_kv0(M, a.inv_n);
+  }
   const float nx = (float)(min(w.gx + 1, d.W - 1) - max(w.gx - 1, 0) + 1);
   // 1 / (taps of the 3x3 SAME window inside the image): k * fl(1/k) == 1 exactly for k = 4, 6, 9
   const float rc3 = 1.0f / (3.0f * nx), rc2 = 1.0f / (2.0f * nx), rc1 = 1.0f / nx;
@@ -497,7 +513,14 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
 // XCD-contiguous order measured 25 % MORE fetched bytes here - profiles/r01_traffic.md).  Two kernels because the register
 // budgets differ (the gather side carries two SSIMs per channel).
 template <bool GRAD>
-__global__ __launch_bounds__(kBlock) SFM_WPE_GATHER void loss_stencil_gather_kernel(StencilArgs a) {
+__global__ __launch_bounds__(kBlock) SFM_WPE_GATHER void loss_stencil_gather_kernel(StencilArgs a, int gather_blocks) {
+  if ((int)blockIdx.x >= gather_blocks) {  // the extra workgroups of a single-device launch: mask-sum fix-up, one wave per tile
+    const long t = (long)(blockIdx.x - gather_blocks) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int ntile = a.stiles_x * a.stiles_y;
+    if (t < (long)a.d.S * a.d.N * a.d.B * ntile)
+      msum_fix_tile(t, threadIdx.x & 63, a.Acc, a.Ovf, a.flags, a.ovl, a.msumt, a.d.H, a.d.W, a.stiles_x, ntile);
+    return;
+  }
   const long w = (long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (w < a.p.n_gather) gather_item<GRAD>(a, w, a.wavep + (a.p.n_splat + w) * kWaveTerms);
 }
@@ -523,7 +546,56 @@ __global__ __launch_bounds__(64) SFM_WPE_SPLAT void loss_stencil_splat_redo_kern
   for (long w = blockIdx.x; w < a.p.n_splat; w += gridDim.x) splat_item<true, true>(a, w, a.wavep, partials);
 }
 
+// per-wave partial sums of the stencil kernels -> partials fp64 [S][3N+1], fixed summation order (deterministic).
+// grid (S, 3N+1): workgroup (s, t) owns one term.  GUARD (single device, where these sums are the global ones): the
+// workgroup that has formed V(s, i) checks the clip and, in the degenerate case that it does not pass, rewrites the seeds
+// of its (scale, source) with kV0 = 0 itself (four waves: slow, and never taken for real images).
+template <bool GUARD>
+__global__ __launch_bounds__(kBlock) SFM_WPE_SPLAT void loss_reduce_kernel(StencilArgs a, double* __restrict__ partials) {
+  __shared__ double red[kBlock];
+  const LossDims d = a.d;
+  const StencilPlan p = a.p;
+  const int s = blockIdx.x, t = blockIdx.y;
+  const int nterm = 3 * d.N + 1;
+  long per = (long)d.B * p.per_img;  // waves per (scale, source) image set
+  long first;
+  int comp;
+  if (t < 3 * d.N) {
+    first = ((long)s * d.N + t / 3) * per;
+    comp = t % 3;
+  } else {
+    per = (long)d.B * p.per_img_g;
+    first = p.n_splat + (long)s * per;
+    comp = 0;
+  }
+  double acc = 0.0;
+  if (t < 3 * d.N || p.n_gather > 0)
+    for (long k = threadIdx.x; k < per; k += kBlock) acc += (double)a.wavep[(first + k) * kWaveTerms + comp];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[(size_t)s * nterm + t] = red[0];
+  if constexpr (GUARD) {
+    if (t < 3 * d.N && comp == 2 && !loss_clip_passes(red[0], a.inv_n)) {  // workgroup-uniform
+      const int i = t / 3;
+      const long per_s = (long)d.B * p.chunks * p.strips;  // items of one scale and source
+      for (long q = threadIdx.x >> 6; q < per_s; q += kBlock / 64)
+        splat_item<true, true>(a, ((long)s * per_s + q) * d.N + i, a.wavep, nullptr);
+    }
+  }
+}
+
 }  // namespace
+
+int launch_loss_reduce(const StencilArgs& a, double* partials, bool guard, hipStream_t stream) {
+  const dim3 grid(a.d.S, 3 * a.d.N + 1);
+  if (guard) hipLaunchKernelGGL(loss_reduce_kernel<true>, grid, dim3(kBlock), 0, stream, a, partials);
+  else hipLaunchKernelGGL(loss_reduce_kernel<false>, grid, dim3(kBlock), 0, stream, a, partials);
+  return sfm_last_error();
+}
 
 int launch_loss_stencil_redo(const StencilArgs& a, const double* partials, hipStream_t stream) {
   hipLaunchKernelGGL(loss_stencil_splat_redo_kernel, dim3(kRedoWaves), dim3(64), 0, stream, a, partials);
@@ -536,13 +608,14 @@ int launch_loss_stencil_redo(const StencilArgs& a, const double* partials, hipSt
 // and cache than the chip has, so they only get in each other's way.
 int launch_loss_stencil(const StencilArgs& a, bool need_grad, int which, hipStream_t stream) {
   constexpr int WPB = kBlock / 64;
-  const dim3 gs((unsigned)((a.p.n_splat + WPB - 1) / WPB)), gg((unsigned)((a.p.n_gather + WPB - 1) / WPB));
+  const int gb = (int)((a.p.n_gather + WPB - 1) / WPB);
+  const dim3 gs((unsigned)((a.p.n_splat + WPB - 1) / WPB)), gg((unsigned)(gb + (need_grad ? a.fix_blocks : 0)));
   const bool gather = (which & kStencilGather) && a.p.n_gather, splat = (which & kStencilSplat) != 0;
   if (need_grad) {
-    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<true>, gg, dim3(kBlock), 0, stream, a);
+    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<true>, gg, dim3(kBlock), 0, stream, a, gb);
     if (splat) hipLaunchKernelGGL(loss_stencil_splat_kernel<true>, gs, dim3(kBlock), 0, stream, a);
   } else {
-    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<false>, gg, dim3(kBlock), 0, stream, a);
+    if (gather) hipLaunchKernelGGL(loss_stencil_gather_kernel<false>, gg, dim3(kBlock), 0, stream, a, gb);
     if (splat) hipLaunchKernelGGL(loss_stencil_splat_kernel<false>, gs, dim3(kBlock), 0, stream, a);
   }
   return sfm_last_error();

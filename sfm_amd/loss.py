@@ -103,7 +103,9 @@ class LossEngine:
             if work is not None:
                 work.wait()  # device tensors: the current stream waits for the collective, not the host
             self.forward_splat(src, n_elem_global, need_grad, msum, partials)
+            self._guarded = False  # the sums are not global yet: the backward applies the seed guard after the all-reduce
             return partials
+        self._guarded = True       # sfm_loss_forward's own reduction applies it (single device: its sums are the global ones)
         st = stream_of(tgt)
         call("sfm_pose_setup", ptr(pose), 6 * N, 6, ptr(K), B, N, 0, ptr(self.params), st)
         if isinstance(depth, (list, tuple)):
@@ -141,13 +143,19 @@ class LossEngine:
              ptr(msum_global), ptr(partials), stream_of(src))
 
     def backward(self, tgt, src, K, depth, pose, trans, partials, n_elem_global: int, gloss: float = 1.0,
-                 need_grad: bool = True, d_trans_into: Optional[Sequence[Tensor]] = None, n_extra: int = 0):
+                 need_grad: bool = True, d_trans_into: Optional[Sequence[Tensor]] = None, n_extra: int = 0,
+                 seeds_guarded: Optional[bool] = None):
         """Second half.  Returns (loss, d_depth, d_pose, d_trans).  Stacked inputs: d_depth [S,B,H,W], d_trans
         [S,B,H,W,3N].  Pyramid LISTS for ``depth`` / ``trans``: the adjoint of the resize runs in the kernel and the
         gradients come back as lists at the pyramid's own sizes (``sfm_loss_backward_pyr``); ``d_trans_into``: maps
         that already hold another term of the translation gradients (the regulariser's), added to in place;
-        ``n_extra``: fp64 values behind the sums in ``partials`` that are added to the loss (pyramid path only)."""
+        ``n_extra``: fp64 values behind the sums in ``partials`` that are added to the loss (pyramid path only).
+        ``seeds_guarded``: whether the forward has already applied the seed guard for these very sums (what the
+        single-call forward of this engine does; default: what the last ``forward_partials`` did) - pass False when
+        ``partials`` were changed since (summed with other ranks', edited by a test)."""
         B, H, W, S, N = self.dims
+        guarded = getattr(self, "_guarded", False) if seeds_guarded is None else seeds_guarded
+        ng = (3 if guarded else 1) if need_grad else 0  # include/sfm_amd.h: bit 1 = guard already applied
         loss = torch.empty((), dtype=torch.float32, device=self.device)
         d_pose = torch.empty_like(pose) if need_grad else None
         if isinstance(depth, (list, tuple)):
@@ -166,13 +174,13 @@ class LossEngine:
                     raise ValueError("d_trans_into: one contiguous map per level, shaped like the level")
                 dd_tab, dt_tab = P._ptrs(d_depth), P._ptrs(d_trans)
             call("sfm_loss_backward_pyr", ptr(tgt), ptr(src), *self._pyr_args(depth, trans), ptr(self.params), ptr(self.ws),
-                 B, H, W, S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), int(n_extra), ptr(pose), ptr(K),
+                 B, H, W, S, N, int(n_elem_global), float(gloss), ng, ptr(partials), int(n_extra), ptr(pose), ptr(K),
                  ptr(loss), dd_tab, dt_tab, ptr(d_pose), stream_of(tgt))
             return loss, d_depth, d_pose, d_trans
         d_depth = torch.empty(S, B, H, W, dtype=torch.float32, device=self.device) if need_grad else None
         d_trans = torch.empty(S, B, H, W, 3 * N, dtype=torch.float32, device=self.device) if need_grad else None
         call("sfm_loss_backward", ptr(tgt), ptr(src), ptr(depth), ptr(trans), ptr(self.params), ptr(self.ws), B, H, W,
-             S, N, int(n_elem_global), float(gloss), int(need_grad), ptr(partials), ptr(pose), ptr(K), ptr(loss),
+             S, N, int(n_elem_global), float(gloss), ng, ptr(partials), ptr(pose), ptr(K), ptr(loss),
              ptr(d_depth), ptr(d_trans), ptr(d_pose), stream_of(tgt))
         return loss, d_depth, d_pose, d_trans
 
