@@ -244,7 +244,17 @@ __global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_t
   // (the barrier that publishes acc / tcache sits after the first pixel's loads have been issued: one memory round trip
   // of the workgroup's start-up less)
 
-  const Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
+  // The 21 pose constants are wave-uniform, so the compiler keeps them in SGPRs - and with the kernel's ~100 other
+  // uniform values spills them into VGPR lanes, re-read with v_readlane inside the scan loop (60 of them, plus hazard
+  // s_nops).  The register budget that matters here is LDS-bound occupancy (4 waves per SIMD = 128 VGPRs, 62 used): pin
+  // the constants into VGPRs instead.
+  Pose ps = load_pose(params + ((size_t)i * d.B + b) * SFM_PARAM_STRIDE);
+#ifndef SFM_SPLAT_POSE_SGPR
+#pragma unroll
+  for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(ps.ki[k]));
+#pragma unroll
+  for (int k = 0; k < 12; ++k) asm volatile("" : "+v"(ps.p[k]));
+#endif
   const size_t imgpix = (size_t)b * HW;              // pixel offset of batch item b
   const size_t sb = ((size_t)s * d.B + b) * HW;      // pixel offset of (s, b)
   const float xmax = (float)(d.W - 1), ymax = (float)(d.H - 1);

@@ -141,9 +141,12 @@ class DataLoader(object):
         rng = random.Random(self.seed)
         pin = self.device.type == "cuda" and torch.cuda.is_available()
         shape = (self.batch_size, self.img_height, (self.num_source + 1) * self.img_width, 3)
-        ring = [(torch.empty(shape, dtype=torch.uint8, pin_memory=pin),
-                 torch.empty(self.batch_size, 3, 3, dtype=torch.float32, pin_memory=pin))
-                for _ in range(self.prefetch + 2)]  # in flight: queue + the one being filled + the one being copied
+        # slot = [pinned images, pinned intrinsics, event of the slot's last host -> device copy (set by the consumer)].
+        # In flight: the queue + the one being filled + the one being copied; a slot comes round again only after the
+        # consumer has taken the batch behind it, i.e. after that event was recorded.
+        ring = [[torch.empty(shape, dtype=torch.uint8, pin_memory=pin),
+                 torch.empty(self.batch_size, 3, 3, dtype=torch.float32, pin_memory=pin), None]
+                for _ in range(self.prefetch + 2)]
         slot, epoch = 0, 0
         with ThreadPoolExecutor(self.num_workers) as pool:
             while epochs is None or epoch < epochs:
@@ -151,7 +154,11 @@ class DataLoader(object):
                 if shuffle:  # one permutation for images and intrinsics (string_input_producer with a shared seed)
                     rng.shuffle(order)
                 for bi in range(n_batches):
-                    img_buf, cam_buf = ring[slot]
+                    entry = ring[slot]
+                    img_buf, cam_buf = entry[0], entry[1]
+                    if entry[2] is not None:   # the copy that last read this pinned buffer: waited for HERE, on the producer
+                        entry[2].synchronize()  # thread (long finished by the time the ring comes round), never by the consumer
+                        entry[2] = None
                     slot = (slot + 1) % len(ring)
                     img_np, cam_np = img_buf.numpy(), cam_buf.numpy()
                     chunk = order[bi * self.batch_size:(bi + 1) * self.batch_size]
@@ -160,7 +167,7 @@ class DataLoader(object):
                         cam_np[j] = self.read_cam_file(c)
                     for job in jobs:
                         job.result()
-                    yield img_buf, cam_buf
+                    yield entry
                 epoch += 1
 
     def _device_batches(self, split: str, augment: bool, shuffle: bool, epochs: Optional[int]) -> Iterator:
@@ -195,7 +202,7 @@ class DataLoader(object):
                     return
                 if isinstance(item, BaseException):
                     raise item
-                img_buf, cam_buf = item
+                img_buf, cam_buf = item[0], item[1]
                 with torch.cuda.stream(copy_stream):
                     seq_d = img_buf.to(self.device, non_blocking=True)
                     cam_d = cam_buf.to(self.device, non_blocking=True)
@@ -207,7 +214,7 @@ class DataLoader(object):
                 draws = AugmentDraws.draw(draw_rng) if augment else None
                 out = snippet_unpack(seq_d, cam_d, self.img_height, self.img_width, self.num_source, self.num_scales,
                                      draws)
-                done.synchronize()  # the pinned buffer returns to the ring only after its copy has finished
+                item[2] = done  # the ring's producer waits for it before it refills the pinned buffer (no host sync here)
                 yield out
         finally:
             stop.set()

@@ -84,7 +84,7 @@ def test_dataloader_end_to_end(dev, tmp_path):
     H, W, n_src, B = 16, 24, 2, 2
     write_snippet_dataset(root, n=7, H=H, W=W, n_src=n_src, seed=11)
     dl = DataLoader(root, B, H, W, n_src, 4, device=dev, seed=5, num_workers=2)
-    host = [(i.clone().numpy(), c.clone().numpy()) for i, c in DataLoader(root, B, H, W, n_src, 4, device="cpu", seed=5)._host_batches("train", True, 2)]
+    host = [(i.clone().numpy(), c.clone().numpy()) for i, c, _ in DataLoader(root, B, H, W, n_src, 4, device="cpu", seed=5)._host_batches("train", True, 2)]
     it = dl.load_train_batch(epochs=2)
     assert dl.steps_per_epoch == 3
     rng = random.Random(6)

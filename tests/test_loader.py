@@ -103,7 +103,7 @@ def test_host_batches_decode_and_order(tmp_path):
     dl = DataLoader(root, 2, 8, 12, 2, 4, device="cpu", seed=7, num_workers=2)
     files = dl.format_file_list(root, "train")
     decoded = {p: np.asarray(Image.open(p).convert("RGB")) for p in files["image_file_list"]}
-    got = [(img.clone().numpy(), cam.clone().numpy()) for img, cam in dl._host_batches("train", True, 2)]
+    got = [(img.clone().numpy(), cam.clone().numpy()) for img, cam, _ in dl._host_batches("train", True, 2)]
     assert len(got) == 4                                                # 2 epochs x (5 // 2) batches
     seen = []
     for img, cam in got:
@@ -114,7 +114,7 @@ def test_host_batches_decode_and_order(tmp_path):
             assert np.array_equal(cam[j], dl.read_cam_file(hit[0][:-4] + "_cam.txt"))   # image and intrinsics stay paired
             seen.append(hit[0])
     assert len(set(seen[:4])) == 4 and len(set(seen[4:])) == 4          # no repeats inside an epoch
-    again = [img.clone().numpy() for img, _ in DataLoader(root, 2, 8, 12, 2, 4, device="cpu", seed=7)._host_batches("train", True, 2)]
+    again = [img.clone().numpy() for img, _, _ in DataLoader(root, 2, 8, 12, 2, 4, device="cpu", seed=7)._host_batches("train", True, 2)]
     assert all(np.array_equal(a, b[0]) for a, b in zip(again, got))     # same seed, same order
 
 
