@@ -255,7 +255,8 @@ int sfm_resize_bilinear_bwd(const float* gout, int B, int h, int w, int C, int H
  * maps[m] [B,h[m],w[m],c[m]] (h, w >= 3); every mean divides by the GLOBAL element count (B_global in
  * place of B).  Value and gradient in one pass: d_maps (NULL, or per map NULL = not wanted) receives
  * gscale * dloss/dmaps[m]; loss_out one float (this rank's share of the global mean).
- * ws: sfm_smooth_workspace_floats(...) floats, contents undefined between calls. */
+ * ws: sfm_smooth_workspace_floats(...) floats, 8-byte aligned (the block shares are fp64), contents undefined between
+ * calls. */
 long long sfm_smooth_workspace_floats(const int* h, const int* w, const int* c, int n_maps, int B);
 int sfm_smooth_loss(const float* const* maps, float* const* d_maps, const int* h, const int* w, const int* c,
                     const float* w_smooth, const float* w_abs, int n_maps, int B, int B_global, float gscale, float* ws,

@@ -139,6 +139,148 @@ __global__ __launch_bounds__(kBlock) void disp_normalize_bwd_kernel(NormArgs a, 
   }
 }
 
+// ---- one launch per direction for pyramids whose items fit a workgroup's registers ---------------------------------
+// (128 x 416 training images: 53 k elements per item at scale 0).  kNormSlices 1024-thread workgroups per (scale, batch
+// item), largest items first.  EVERY workgroup of an item sums the whole item (16 float4 per thread, all loads in flight,
+// the same order in each: identical means without any exchange) and applies the result to its own quarter, which still
+// sits in its registers - the divisions, which are the cost, are spread over 4 x as many CUs as there are items, and no
+// partial sums go through memory: 2 launches of ~6 us -> one.  Items beyond kNormOneMax elements or not a multiple of 4
+// take the chunked pair above.
+constexpr int kNormOneThreads = 1024;
+constexpr int kNormSlots = 16;
+constexpr int kNormSlices = 4;
+constexpr int kNormOwn = kNormSlots / kNormSlices;
+constexpr int kNormOneMax = kNormOneThreads * kNormSlots * 4;
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < kNormOneThreads / 64; ++k) t += red[k];
+  return t;
+}
+
+template <int Q>
+__device__ __forceinline__ void normalize_fwd_slice(const NormArgs& a, int s, int b, float* __restrict__ mean, float* red) {
+  const int n4 = a.n[s] >> 2;
+  const size_t base = (size_t)b * a.n[s];
+  const float4* __restrict__ d = reinterpret_cast<const float4*>(a.disp[s] + base);
+  float4* __restrict__ dn = reinterpret_cast<float4*>(a.dispn[s] + base);
+  float4* __restrict__ dp = reinterpret_cast<float4*>(a.depth[s] + base);
+  float4 v[kNormSlots];
+#pragma unroll
+  for (int j = 0; j < kNormSlots; ++j) {
+    const int k = j * kNormOneThreads + threadIdx.x;
+    v[j] = d[min(k, n4 - 1)];  // unconditional, selected below (see the backward)
+  }
+#pragma unroll
+  for (int j = 0; j < kNormSlots; ++j)
+    if (j * kNormOneThreads + (int)threadIdx.x >= n4) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < kNormSlots; ++j) acc += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float m = block_sum_1024(acc, red) / (float)a.n[s];
+  if (Q == 0 && threadIdx.x == 0) mean[s * a.B + b] = m;
+#pragma unroll
+  for (int j = Q * kNormOwn; j < (Q + 1) * kNormOwn; ++j) {
+    const int k = j * kNormOneThreads + threadIdx.x;
+    if (k < n4) {
+      const float4 q = make_float4(v[j].x / m, v[j].y / m, v[j].z / m, v[j].w / m);
+      dn[k] = q;
+      dp[k] = make_float4(1.0f / q.x, 1.0f / q.y, 1.0f / q.z, 1.0f / q.w);
+    }
+  }
+}
+__global__ __launch_bounds__(kNormOneThreads) void disp_normalize_fwd_item_kernel(NormArgs a, float* __restrict__ mean) {
+  __shared__ float red[kNormOneThreads / 64];
+  const int item = blockIdx.x / kNormSlices, q = blockIdx.x - item * kNormSlices;
+  const int s = item / a.B, b = item - s * a.B;
+  switch (q) {  // the slice as a compile-time constant: its slots of v[] are then registers, not an indexed array
+    case 0: normalize_fwd_slice<0>(a, s, b, mean, red); break;
+    case 1: normalize_fwd_slice<1>(a, s, b, mean, red); break;
+    case 2: normalize_fwd_slice<2>(a, s, b, mean, red); break;
+    default: normalize_fwd_slice<3>(a, s, b, mean, red); break;
+  }
+}
+
+// dL/du = g_dispn - g_depth * depth^2 (the form autodiff of 1 / u takes: -g y^2 with the forward's y), depth = m / d by
+// v_rcp_f32: an IEEE division costs ~11 instructions and two mode-register writes on this part, and a workgroup here
+// evaluates 64 elements per thread (144 divisions per thread took 33 us; this form 6)
+__device__ __forceinline__ float norm_t(float d, float gu, float gd, float m, bool has_gd) {
+  float t = gu;
+  if (has_gd) {
+    const float y = m * __builtin_amdgcn_rcpf(d);
+    t -= gd * (y * y);
+  }
+  return t;
+}
+template <int Q>
+__device__ __forceinline__ void normalize_bwd_slice(const NormArgs& a, int s, int b, const float* __restrict__ mean, float* red) {
+  const int n4 = a.n[s] >> 2;
+  const size_t base = (size_t)b * a.n[s];
+  const float m = mean[s * a.B + b];
+  const float4* __restrict__ d = reinterpret_cast<const float4*>(a.disp[s] + base);
+  const float4* __restrict__ gu = a.g_dispn[s] ? reinterpret_cast<const float4*>(a.g_dispn[s] + base) : nullptr;
+  const float4* __restrict__ gd = a.g_depth[s] ? reinterpret_cast<const float4*>(a.g_depth[s] + base) : nullptr;
+  float4* __restrict__ g = reinterpret_cast<float4*>(a.g_disp[s] + base);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* __restrict__ gup = gu ? gu : d;  // (a missing gradient: any readable address, the value is dropped)
+  const float4* __restrict__ gdp = gd ? gd : d;
+  float4 own[kNormOwn];
+  float acc = 0.f;
+  constexpr int kGroup = kNormOwn;  // chunks whose three loads are in flight together (48 registers); NOT unrolled over
+                                    // the groups: the compiler then hoists all 48 loads and spills at 1024 threads
+#pragma unroll 1
+  for (int j0 = 0; j0 < kNormSlots; j0 += kGroup) {
+    float4 dv[kGroup], uv[kGroup], dd[kGroup];
+#pragma unroll
+    for (int jj = 0; jj < kGroup; ++jj) {
+      // unconditional loads at a clamped index, selected afterwards: a guarded load is a branch with its own wait, and
+      // the 12 loads of a group then go one round trip at a time (29 us instead of 6)
+      const int k = (j0 + jj) * kNormOneThreads + threadIdx.x;
+      const int kc = min(k, n4 - 1);
+      dv[jj] = d[kc];
+      uv[jj] = gup[kc];
+      dd[jj] = gdp[kc];
+    }
+#pragma unroll
+    for (int jj = 0; jj < kGroup; ++jj) {
+      const bool in = (j0 + jj) * kNormOneThreads + (int)threadIdx.x < n4;
+      if (!(in && gu)) uv[jj] = z4;
+      if (!(in && gd)) dd[jj] = z4;
+    }
+#pragma unroll
+    for (int jj = 0; jj < kGroup; ++jj) {
+      const float4 t = make_float4(norm_t(dv[jj].x, uv[jj].x, dd[jj].x, m, gd != nullptr), norm_t(dv[jj].y, uv[jj].y, dd[jj].y, m, gd != nullptr),
+                                   norm_t(dv[jj].z, uv[jj].z, dd[jj].z, m, gd != nullptr), norm_t(dv[jj].w, uv[jj].w, dd[jj].w, m, gd != nullptr));
+      acc += (t.x * dv[jj].x + t.y * dv[jj].y) + (t.z * dv[jj].z + t.w * dv[jj].w);  // (elements beyond the item: t = 0)
+      if (j0 == Q * kNormOwn) own[jj] = t;
+    }
+  }
+  const float corr = block_sum_1024(acc, red) / ((m * m) * (float)a.n[s]);
+  const float rm = 1.0f / m;
+#pragma unroll
+  for (int j = 0; j < kNormOwn; ++j) {
+    const int k = (Q * kNormOwn + j) * kNormOneThreads + threadIdx.x;
+    if (k < n4) g[k] = make_float4(own[j].x * rm - corr, own[j].y * rm - corr, own[j].z * rm - corr, own[j].w * rm - corr);
+  }
+}
+__global__ __launch_bounds__(kNormOneThreads) void disp_normalize_bwd_item_kernel(NormArgs a, const float* __restrict__ mean) {
+  __shared__ float red[kNormOneThreads / 64];
+  const int item = blockIdx.x / kNormSlices, q = blockIdx.x - item * kNormSlices;
+  const int s = item / a.B, b = item - s * a.B;
+  switch (q) {
+    case 0: normalize_bwd_slice<0>(a, s, b, mean, red); break;
+    case 1: normalize_bwd_slice<1>(a, s, b, mean, red); break;
+    case 2: normalize_bwd_slice<2>(a, s, b, mean, red); break;
+    default: normalize_bwd_slice<3>(a, s, b, mean, red); break;
+  }
+}
+
 // ------------------------------------------------------------------ bilinear upsample of the pyramid
 // tf.image.resize_bilinear, TF-1 defaults (align_corners=False, no half-pixel centres), resize_bilinear_op.cc:
 //   scale = in / (float)out;  src = dst * scale;  lo = floor(src);  hi = min(lo + 1, in - 1);  lerp = src - lo
@@ -489,8 +631,13 @@ __device__ __forceinline__ void smooth_run(const SmoothK& c, const float* __rest
   }
 }
 
-__global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, float* __restrict__ blockp) {
+struct SmoothCoef {  // weight / (global element count) of every (map, term), fp64, formed on the host
+  double k[kMaxMaps * kSmoothTerms];
+};
+// blockp[block] = the block's share of the regulariser: its 7 term sums (fp32, fixed order) weighted in fp64
+__global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, SmoothCoef kc, double* __restrict__ blockp) {
   __shared__ float red[4 * kSmoothTerms];
+  __shared__ float tot[kSmoothTerms];
   int m = 0;
   while (m + 1 < a.n_maps && (int)blockIdx.x >= a.blk0[m + 1]) ++m;
   const unsigned h = a.h[m], w = a.w[m], C = a.c[m];
@@ -517,47 +664,41 @@ __global__ __launch_bounds__(kBlock) void smooth_loss_kernel(SmoothArgs a, float
         smooth_run<1>(c, img, gimg, (int)C, (int)ch, (int)x, (int)(yg * kSmoothRun), (int)w, (int)h, a.gscale, t);
     }
   }
-  block_sum_store<kSmoothTerms>(t, red, blockp + (size_t)blockIdx.x * kSmoothTerms);
+  block_sum_store<kSmoothTerms>(t, red, tot);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < kSmoothTerms; ++j) v += (double)tot[j] * kc.k[m * kSmoothTerms + j];
+    blockp[blockIdx.x] = v;
+  }
 }
 
-// one workgroup of 16 waves: wave v sums the block partials of the (map, term) pairs v, v+16, ... (lanes stride
-// over the blocks, then a shuffle tree: a fixed order) and weights the sum with coef / denominator (formed on the host
-// in fp64); wave 0 adds the <= 112 weighted terms, again in a fixed order
-constexpr int kSmoothReduceThreads = 1024;
-struct SmoothCoef {
-  double k[kMaxMaps * kSmoothTerms];
-};
-__global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(SmoothArgs a, SmoothCoef kc,
-                                                                             const float* __restrict__ blockp,
+// one workgroup adds the block shares: thread-strided fp64 sums, then a fixed-order tree
+constexpr int kSmoothReduceThreads = 256;
+__global__ __launch_bounds__(kSmoothReduceThreads) void smooth_reduce_kernel(int nblk, const double* __restrict__ blockp,
                                                                              float* __restrict__ loss_out,
                                                                              double* __restrict__ loss_out_f64) {
-  __shared__ double psum[kMaxMaps * kSmoothTerms];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int npair = a.n_maps * kSmoothTerms;
-  for (int pr = wave; pr < npair; pr += kSmoothReduceThreads / 64) {
-    const int m = pr / kSmoothTerms, j = pr - m * kSmoothTerms;
-    double acc0 = 0.0, acc1 = 0.0;
-    int k = a.blk0[m] + lane;
-    for (; k + 64 < a.blk0[m + 1]; k += 128) {  // two loads in flight per lane
-      acc0 += (double)blockp[(size_t)k * kSmoothTerms + j];
-      acc1 += (double)blockp[(size_t)(k + 64) * kSmoothTerms + j];
-    }
-    if (k < a.blk0[m + 1]) acc0 += (double)blockp[(size_t)k * kSmoothTerms + j];
-    double acc = acc0 + acc1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) psum[pr] = acc * kc.k[pr];
+  __shared__ double red[kSmoothReduceThreads];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four loads in flight per thread
+  int k = threadIdx.x;
+  for (; k + 3 * kSmoothReduceThreads < nblk; k += 4 * kSmoothReduceThreads) {
+    a0 += blockp[k];
+    a1 += blockp[k + kSmoothReduceThreads];
+    a2 += blockp[k + 2 * kSmoothReduceThreads];
+    a3 += blockp[k + 3 * kSmoothReduceThreads];
   }
+  for (; k < nblk; k += kSmoothReduceThreads) a0 += blockp[k];
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (wave == 0) {
-    double total = 0.0;
-    for (int k = lane; k < npair; k += 64) total += psum[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
-    if (lane == 0) {
-      if (loss_out) *loss_out = (float)total;
-      if (loss_out_f64) *loss_out_f64 = (double)(float)total;  // the fp32 value, in the all-reduce buffer's type
-    }
+  for (int o = kSmoothReduceThreads / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double total = red[0];
+    if (loss_out) *loss_out = (float)total;
+    if (loss_out_f64) *loss_out_f64 = (double)(float)total;  // the fp32 value, in the all-reduce buffer's type
   }
 }
 
@@ -753,6 +894,17 @@ static int fill_norm(NormArgs& a, const float* const* disp, const int* n, int S,
   return SFM_OK;
 }
 
+// every item a multiple of 4 elements, at most kNormOneMax, every listed pointer 16-byte aligned: the one-launch form
+static bool norm_one_launch(const NormArgs& a) {
+  for (int s = 0; s < a.S; ++s) {
+    if (a.n[s] % 4 || a.n[s] > kNormOneMax) return false;
+    const void* ps[6] = {a.disp[s], a.dispn[s], a.depth[s], a.g_dispn[s], a.g_depth[s], a.g_disp[s]};
+    for (const void* q : ps)
+      if ((uintptr_t)q & 15) return false;
+  }
+  return (long)a.S * a.B * kNormSlices <= 2147483647L;
+}
+
 extern "C" long long sfm_disp_normalize_workspace_floats(const int* n, int S, int B) {
   if (!n || S < 1 || S > kMaxMaps || B < 1) return SFM_ERR_ARG;
   long chunk = 0;
@@ -774,6 +926,11 @@ extern "C" int sfm_disp_normalize_fwd(const float* const* disp, const int* n, in
     a.dispn[s] = disp_norm[s];
     a.depth[s] = depth[s];
   }
+  if (norm_one_launch(a)) {
+    hipLaunchKernelGGL(disp_normalize_fwd_item_kernel, dim3((unsigned)(S * B * kNormSlices)), dim3(kNormOneThreads), 0, (hipStream_t)stream, a,
+                       mean);
+    return sfm_last_error();
+  }
   const dim3 grid((unsigned)a.chunk0[S]);
   hipLaunchKernelGGL(disp_partial_kernel<0>, grid, dim3(kBlock), 0, (hipStream_t)stream, a, (const float*)nullptr, ws);
   hipLaunchKernelGGL(disp_normalize_fwd_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a, ws, mean);
@@ -792,6 +949,11 @@ extern "C" int sfm_disp_normalize_bwd(const float* const* disp, const float* mea
     a.g_disp[s] = g_disp[s];
     a.g_dispn[s] = g_disp_norm ? g_disp_norm[s] : nullptr;
     a.g_depth[s] = g_depth ? g_depth[s] : nullptr;
+  }
+  if (norm_one_launch(a)) {
+    hipLaunchKernelGGL(disp_normalize_bwd_item_kernel, dim3((unsigned)(S * B * kNormSlices)), dim3(kNormOneThreads), 0, (hipStream_t)stream, a,
+                       mean);
+    return sfm_last_error();
   }
   const dim3 grid((unsigned)a.chunk0[S]);
   hipLaunchKernelGGL(disp_partial_kernel<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, a, mean, ws);
@@ -831,7 +993,8 @@ extern "C" int sfm_smooth_loss(const float* const* maps, float* const* d_maps, c
   SmoothArgs a;
   const int rc = fill_smooth(a, h, w, c, n_maps, B);
   if (rc) return rc;
-  if (!maps || !w_smooth || !w_abs || !ws || (!loss_out && !loss_out_f64) || B_global < B) return SFM_ERR_ARG;
+  if (!maps || !w_smooth || !w_abs || !ws || ((uintptr_t)ws & 7) || (!loss_out && !loss_out_f64) || B_global < B)
+    return SFM_ERR_ARG;
   for (int m = 0; m < n_maps; ++m) {
     if (!maps[m]) return SFM_ERR_ARG;
     a.map[m] = maps[m];
@@ -852,8 +1015,9 @@ extern "C" int sfm_smooth_loss(const float* const* maps, float* const* d_maps, c
     const double* k = kc.k + m * kSmoothTerms;  // the same quotients, rounded once, weight the gradient
     a.kk[m] = SmoothK{(float)k[0], (float)k[1], (float)k[2], (float)k[5], (float)k[3], (float)k[6]};
   }
-  hipLaunchKernelGGL(smooth_loss_kernel, dim3((unsigned)a.blk0[n_maps]), dim3(kBlock), 0, (hipStream_t)stream, a, ws);
-  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(1), dim3(kSmoothReduceThreads), 0, (hipStream_t)stream, a, kc, ws, loss_out,
-                     loss_out_f64);
+  double* blockp = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(smooth_loss_kernel, dim3((unsigned)a.blk0[n_maps]), dim3(kBlock), 0, (hipStream_t)stream, a, kc, blockp);
+  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(1), dim3(kSmoothReduceThreads), 0, (hipStream_t)stream, a.blk0[n_maps], blockp,
+                     loss_out, loss_out_f64);
   return sfm_last_error();
 }
