@@ -283,6 +283,14 @@ int sfm_aspp_conv3x3_bwd_data(const float* gout, const float* w, int B, int H, i
                               float* gin, float* ws, void* stream);
 int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, int rate,
                                 float* gw, float* ws, void* stream);
+/* The forward and the weight gradient with `in` a CHANNEL SLICE of a wider NHWC buffer: in = address of the slice's first
+ * channel at pixel 0 (16-byte aligned), ld_in = floats between consecutive pixels (a multiple of 4, >= Cin).  This is how
+ * the decoder level reads tf.concat([supnet, aspp_up], 3) (nets.py:458) and tf.concat([aspp_up, aspp_up2], 3) (:463)
+ * without a concat: the operands already lie side by side in the level's one concat buffer (:467, 469). */
+int sfm_aspp_conv3x3_fwd_ld(const float* in, int ld_in, const float* w, int B, int H, int W, int Cin, int Cout, int rate,
+                            float* out, float* ws, void* stream);
+int sfm_aspp_conv3x3_bwd_weight_ld(const float* in, int ld_in, const float* gout, int B, int H, int W, int Cin, int Cout,
+                                   int rate, float* gw, float* ws, void* stream);
 
 /* The same slim.conv2d under is_training=False (the inference graphs, test_kitti_depth_con.py:19-65; arg-scope
  * nets.py:653-656 -> resnet/resnet_utils.py:232-251): convolution, batch norm on the moving statistics
@@ -332,6 +340,18 @@ int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* beta, long l
 int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
                    const float* save_invstd, long long M, int C, int act, float* gx, float* ggamma, float* gbeta,
                    float* ws, void* stream);
+/* The same pair for the concat-free decoder level (tf.concat of nets.py:458, 463, 467, 469 never materialised): the
+ * forward writes y as a channel slice of the level's concat buffer (y = address of the slice at row 0, ld_y = floats
+ * between rows: a multiple of 4, >= C, 16-byte aligned); the backward reads y from there and takes dL/dy as the SUM of
+ * n_gy <= 3 tensors gy[k], each a channel slice with its own row stride ld_gy[k] - the slice of the concat buffer's
+ * gradient plus the input gradients of the convolutions that read the same activation - which is the add_n TF's
+ * autodiff inserts for a tensor with several consumers.  x, gx stay dense [M, C]. */
+int sfm_bn_elu_fwd_ld(const float* x, const float* gamma, const float* beta, long long M, int C, float eps, double decay,
+                      int act, float* moving_mean, float* moving_var, float* y, int ld_y, float* save_mean,
+                      float* save_invstd, float* ws, void* stream);
+int sfm_bn_elu_bwd_ld(const float* x, const float* y, int ld_y, const float* const* gy, const int* ld_gy, int n_gy,
+                      const float* gamma, const float* save_mean, const float* save_invstd, long long M, int C, int act,
+                      float* gx, float* ggamma, float* gbeta, float* ws, void* stream);
 
 /* The same batch norm with its statistics taken over ALL ranks of a data-parallel job (the batch of
  * SfMLearner_uni.py:36-45 sharded over GPUs; the reference is single-device, so this is its graph on the global

@@ -59,6 +59,8 @@ SIGNATURES = {
     "sfm_aspp_conv3x3_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv3x3_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_aspp_conv3x3_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_aspp_conv3x3_fwd_ld": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "sfm_aspp_conv3x3_bwd_weight_ld": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sfm_disp_normalize_workspace_floats": [_P, _I, _I],
     "sfm_disp_normalize_fwd": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     "sfm_disp_normalize_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
@@ -81,6 +83,8 @@ SIGNATURES = {
     "sfm_bn_elu_workspace_floats": [_LL, _I],
     "sfm_bn_elu_fwd": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P, _P],
     "sfm_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P],
+    "sfm_bn_elu_fwd_ld": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _I, _P, _P, _P, _P],
+    "sfm_bn_elu_bwd_ld": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P],
     "sfm_bn_local_stats": [_P, _LL, _I, _P, _P, _P],
     "sfm_bn_elu_apply_stats": [_P, _P, _P, _P, _I, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P],
     "sfm_bn_elu_bwd_sums": [_P, _P, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P],

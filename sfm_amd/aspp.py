@@ -327,17 +327,258 @@ def _slim_conv(x, p, name, rate=None, activation=True, process_group=None):
                           process_group=process_group)
 
 
+# ---- one decoder level as ONE autograd node, without a single concat ---------------------------------------------------
+# The activations tf.concat joins (nets.py:458, 463, 467, 469) are written by their batch-norm kernels straight into channel
+# slices of one [B,H,W,4C or 5C] buffer; the convolutions that read a concat of some of them read a slice of that buffer
+# (row stride = the buffer's width); in the backward the gradient of the buffer comes out of the last 1x1 convolution in
+# one piece, every batch norm reads its slice of it and ADDS the input gradients of the convolutions that also read its
+# activation while loading (up to three sources): no torch.cat, no slice copies, no gradient-accumulation passes.
+
+def _raw_resize(x, H, W):
+    B, h, w, C = x.shape
+    out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+    call("sfm_resize_bilinear_fwd", ptr(x), B, h, w, C, H, W, ptr(out), stream_of(x))
+    return out
+
+
+def _raw_resize_bwd(g, h, w):
+    B, H, W, C = g.shape
+    gin = torch.empty(B, h, w, C, dtype=torch.float32, device=g.device)
+    ws = torch.empty(_lib.load().sfm_resize_bilinear_bwd_workspace_floats(B, h, w, C, H, W), dtype=torch.float32, device=g.device)
+    call("sfm_resize_bilinear_bwd", ptr(g), B, h, w, C, H, W, ptr(gin), ptr(ws), stream_of(g))
+    return gin
+
+
+def _raw_conv(x, ld, w, dims, rate):
+    """x: a tensor whose data pointer is the first channel of the operand at pixel 0; ld: its row stride in floats"""
+    B, H, W = dims
+    taps, Cin, Cout = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+    ws = _workspace(B, H, W, Cin, Cout, x.device)
+    out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+    if taps == 1:
+        assert ld == Cin
+        call("sfm_aspp_conv1x1_fwd", ptr(x), ptr(w), B, H, W, Cin, Cout, ptr(out), ptr(ws), stream_of(x))
+    else:
+        call("sfm_aspp_conv3x3_fwd_ld", ptr(x), ld, ptr(w), B, H, W, Cin, Cout, rate, ptr(out), ptr(ws), stream_of(x))
+    return out
+
+
+def _raw_conv_bwd(x, ld, w, gout, dims, rate):
+    """-> (dL/dx dense [B,H,W,Cin], dL/dw in the parameter's gradient slot)"""
+    B, H, W = dims
+    taps, Cin, Cout = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+    ws = _workspace(B, H, W, Cin, Cout, gout.device)
+    gx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=gout.device)
+    gw = _grad_out(w)
+    st = stream_of(gout)
+    if taps == 1:
+        call("sfm_aspp_conv1x1_bwd_data", ptr(gout), ptr(w), B, H, W, Cin, Cout, ptr(gx), ptr(ws), st)
+        call("sfm_aspp_conv1x1_bwd_weight", ptr(x), ptr(gout), B, H, W, Cin, Cout, ptr(gw), ptr(ws), st)
+    else:
+        call("sfm_aspp_conv3x3_bwd_data", ptr(gout), ptr(w), B, H, W, Cin, Cout, rate, ptr(gx), ptr(ws), st)
+        call("sfm_aspp_conv3x3_bwd_weight_ld", ptr(x), ld, ptr(gout), B, H, W, Cin, Cout, rate, ptr(gw), ptr(ws), st)
+    return gx, gw
+
+
+def _raw_bn(x, q, act, y, ld_y):
+    """batch norm (+ ELU) of the dense x into y (a tensor of its own or a channel slice, row stride ld_y) -> (mean, invstd)"""
+    C = x.shape[-1]
+    M = x.numel() // C
+    n_ws = _lib.load().sfm_bn_elu_workspace_floats(M, C)
+    if n_ws < 0:
+        raise ValueError(f"unsupported batch-norm shape M={M} C={C} (C must be a multiple of 4)")
+    ws = torch.empty(n_ws // 2 + 1, dtype=torch.float64, device=x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    call("sfm_bn_elu_fwd_ld", ptr(x), ptr(q["gamma"]), ptr(q["beta"]), M, C, float(BN_EPSILON), float(BN_DECAY), int(act),
+         ptr(q.get("moving_mean")), ptr(q.get("moving_var")), ptr(y), ld_y, ptr(mean), ptr(invstd), ptr(ws), stream_of(x))
+    return mean, invstd
+
+
+def _raw_bn_bwd(x, y, ld_y, srcs, q, stats, act):
+    """srcs: [(tensor whose data pointer is the slice's first channel at row 0, row stride)], summed while loading"""
+    import ctypes
+    C = x.shape[-1]
+    M = x.numel() // C
+    ws = torch.empty(_lib.load().sfm_bn_elu_workspace_floats(M, C) // 2 + 1, dtype=torch.float64, device=x.device)
+    gx = torch.empty_like(x)
+    gg, gb = _grad_out(q["gamma"]), _grad_out(q["beta"])
+    n = len(srcs)
+    gy = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in srcs])
+    ld = (ctypes.c_int * n)(*[int(l) for _, l in srcs])
+    call("sfm_bn_elu_bwd_ld", ptr(x), ptr(y), ld_y, gy, ld, n, ptr(q["gamma"]), ptr(stats[0]), ptr(stats[1]), M, C, int(act),
+         ptr(gx), ptr(gg), ptr(gb), ptr(ws), stream_of(x))
+    return gx, gg, gb
+
+
+_LEVEL_CONVS = ("up", "sup", "aspp_up", "aspp_up2", "skip", "skip2", "out")
+
+
+class _DenseLevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, concat, skip_feat, skip2, *flat):
+        names, rates, use_skip, use_skip2, extras = cfg
+        ctx.set_materialize_grads(False)
+        # name -> dict(w, gamma, beta) / dict(gamma, beta) for 'skip_bn', plus the moving statistics (not differentiated)
+        P, k = {}, 0
+        for nm in names:
+            keys = ("gamma", "beta") if nm == "skip_bn" else ("w", "gamma", "beta")
+            P[nm] = dict(zip(keys, flat[k:k + len(keys)]), **extras.get(nm, {}))
+            k += len(keys)
+        B, h, w_, _ = concat.shape
+        H, W = 2 * h, 2 * w_
+        dims = (B, H, W)
+        C = P["sup"]["w"].shape[3]
+        nC = (5 if use_skip2 else 4) * C
+        with torch.cuda.device(concat.device):
+            u0 = _raw_resize(concat, H, W)                                                      # :454
+            a_up = _raw_conv(u0, u0.shape[3], P["up"]["w"], dims, 0)                            # :455
+            upnet = torch.empty_like(a_up)
+            st = {"up": _raw_bn(a_up, P["up"], 0, upnet, upnet.shape[3])}
+            X = torch.empty(B, H, W, nC, dtype=torch.float32, device=concat.device)            # the level's ONE concat buffer
+            sl = lambda a, b: X[..., a * C:b * C]                                               # noqa: E731  (views: pointers only)
+            a_sup = _raw_conv(upnet, upnet.shape[3], P["sup"]["w"], dims, 0)                    # :456
+            st["sup"] = _raw_bn(a_sup, P["sup"], 1, sl(0, 1), nC)
+            a_au = _raw_conv(upnet, upnet.shape[3], P["aspp_up"]["w"], dims, rates[0])          # :457
+            st["aspp_up"] = _raw_bn(a_au, P["aspp_up"], 1, sl(1, 2), nC)
+            a_au2 = _raw_conv(sl(0, 2), nC, P["aspp_up2"]["w"], dims, rates[1])                 # :458 reads [supnet, aspp_up]
+            st["aspp_up2"] = _raw_bn(a_au2, P["aspp_up2"], 1, sl(2, 3), nC)
+            sk = None
+            if use_skip:
+                sk = torch.empty_like(skip_feat)
+                st["skip_bn"] = _raw_bn(skip_feat, P["skip_bn"], 1, sk, sk.shape[3])            # :460
+                a_sk = _raw_conv(sk, sk.shape[3], P["skip"]["w"], dims, 0)                      # :461
+            else:
+                a_sk = _raw_conv(sl(1, 3), nC, P["skip"]["w"], dims, rates[1] * 2)              # :463 reads [aspp_up, aspp_up2]
+            st["skip"] = _raw_bn(a_sk, P["skip"], 1, sl(3, 4), nC)
+            s2 = a_s2 = None
+            if use_skip2:
+                s2 = _raw_resize(skip2, H, W)                                                   # :465
+                a_s2 = _raw_conv(s2, s2.shape[3], P["skip2"]["w"], dims, 0)                     # :466
+                st["skip2"] = _raw_bn(a_s2, P["skip2"], 1, sl(4, 5), nC)
+            a_out = _raw_conv(X, nC, P["out"]["w"], dims, 0)                                    # :470 reads the whole buffer
+            xconcat = torch.empty_like(a_out)
+            st["out"] = _raw_bn(a_out, P["out"], 0, xconcat, C)
+        ctx.cfg, ctx.P, ctx.st = cfg, P, st
+        ctx.acts = (u0, a_up, a_sup, a_au, a_au2, sk, a_sk, s2, a_s2, X, a_out)
+        ctx.io = (concat.shape, skip2.shape if use_skip2 else None)
+        ctx.save_for_backward(xconcat, upnet, *([skip_feat] if use_skip else []))
+        return xconcat, upnet
+
+    @staticmethod
+    def backward(ctx, g_x, g_up):
+        names, rates, use_skip, use_skip2, _ = ctx.cfg
+        P, st = ctx.P, ctx.st
+        xconcat, upnet = ctx.saved_tensors[:2]
+        skip_feat = ctx.saved_tensors[2] if use_skip else None
+        u0, a_up, a_sup, a_au, a_au2, sk, a_sk, s2, a_s2, X, a_out = ctx.acts
+        concat_shape, skip2_shape = ctx.io
+        B, H, W, C = xconcat.shape
+        dims = (B, H, W)
+        nC = X.shape[3]
+        G = {}
+        with torch.cuda.device(xconcat.device):
+            if g_x is None:
+                g_x = torch.zeros_like(xconcat)
+            g_x = g_x.contiguous()
+            g_a, G["out.gamma"], G["out.beta"] = _raw_bn_bwd(a_out, xconcat, C, [(g_x, C)], P["out"], st["out"], 0)
+            gX, G["out.w"] = _raw_conv_bwd(X, nC, P["out"]["w"], g_a, dims, 0)                  # dL/d(concat buffer), one piece
+            gsl = lambda a: (gX[..., a * C:(a + 1) * C], nC)                                    # noqa: E731
+            ysl = lambda a: X[..., a * C:(a + 1) * C]                                           # noqa: E731
+            g_skip2 = None
+            if use_skip2:
+                g_a, G["skip2.gamma"], G["skip2.beta"] = _raw_bn_bwd(a_s2, ysl(4), nC, [gsl(4)], P["skip2"], st["skip2"], 1)
+                g_s2, G["skip2.w"] = _raw_conv_bwd(s2, s2.shape[3], P["skip2"]["w"], g_a, dims, 0)
+                g_skip2 = _raw_resize_bwd(g_s2, skip2_shape[1], skip2_shape[2])
+            g_a, G["skip.gamma"], G["skip.beta"] = _raw_bn_bwd(a_sk, ysl(3), nC, [gsl(3)], P["skip"], st["skip"], 1)
+            g_skip_feat, t4 = None, None
+            if use_skip:
+                g_sk, G["skip.w"] = _raw_conv_bwd(sk, sk.shape[3], P["skip"]["w"], g_a, dims, 0)
+                g_skip_feat, G["skip_bn.gamma"], G["skip_bn.beta"] = _raw_bn_bwd(skip_feat, sk, sk.shape[3], [(g_sk, sk.shape[3])],
+                                                                                P["skip_bn"], st["skip_bn"], 1)
+            else:
+                t4, G["skip.w"] = _raw_conv_bwd(ysl(1), nC, P["skip"]["w"], g_a, dims, rates[1] * 2)   # -> [aspp_up, aspp_up2]
+            src = [gsl(2)] + ([(t4[..., C:], 2 * C)] if t4 is not None else [])
+            g_a, G["aspp_up2.gamma"], G["aspp_up2.beta"] = _raw_bn_bwd(a_au2, ysl(2), nC, src, P["aspp_up2"], st["aspp_up2"], 1)
+            t5, G["aspp_up2.w"] = _raw_conv_bwd(ysl(0), nC, P["aspp_up2"]["w"], g_a, dims, rates[1])   # -> [supnet, aspp_up]
+            src = [gsl(1), (t5[..., C:], 2 * C)] + ([(t4, 2 * C)] if t4 is not None else [])
+            g_a, G["aspp_up.gamma"], G["aspp_up.beta"] = _raw_bn_bwd(a_au, ysl(1), nC, src, P["aspp_up"], st["aspp_up"], 1)
+            g_u1, G["aspp_up.w"] = _raw_conv_bwd(upnet, upnet.shape[3], P["aspp_up"]["w"], g_a, dims, rates[0])
+            g_a, G["sup.gamma"], G["sup.beta"] = _raw_bn_bwd(a_sup, ysl(0), nC, [gsl(0), (t5, 2 * C)], P["sup"], st["sup"], 1)
+            g_u2, G["sup.w"] = _raw_conv_bwd(upnet, upnet.shape[3], P["sup"]["w"], g_a, dims, 0)
+            Cu = upnet.shape[3]
+            src = [(g_u1, Cu), (g_u2, Cu)] + ([(g_up.contiguous(), Cu)] if g_up is not None else [])
+            g_a, G["up.gamma"], G["up.beta"] = _raw_bn_bwd(a_up, upnet, Cu, src, P["up"], st["up"], 0)
+            g_u0, G["up.w"] = _raw_conv_bwd(u0, u0.shape[3], P["up"]["w"], g_a, dims, 0)
+            g_concat = _raw_resize_bwd(g_u0, concat_shape[1], concat_shape[2])
+        flat = []
+        for nm in names:
+            for key in (("gamma", "beta") if nm == "skip_bn" else ("w", "gamma", "beta")):
+                flat.append(G[f"{nm}.{key}"])
+        return (None, g_concat, g_skip_feat, g_skip2, *flat)
+
+
+def _dense_level(params, concat, skip_feat, rates, use_skip, use_skip2, skip2):
+    names = [n for n in _LEVEL_CONVS if n != "skip2" or use_skip2] + (["skip_bn"] if use_skip else [])
+    concat = _check(concat, "concat", 4)
+    B, h, w_ = concat.shape[:3]
+    C, Cin = params["sup"]["w"].shape[3], params["up"]["w"].shape[3]
+    nsl = 5 if use_skip2 else 4
+    if use_skip:
+        skip_feat = _check(skip_feat, "skip_feat", 4)
+        if tuple(skip_feat.shape[:3]) != (B, 2 * h, 2 * w_):
+            raise ValueError(f"skip_feat must be [B, {2 * h}, {2 * w_}, C], got {tuple(skip_feat.shape)}")
+    if use_skip2:
+        skip2 = _check(skip2, "skip2", 4)
+        if skip2.shape[0] != B or skip2.shape[1] > 2 * h or skip2.shape[2] > 2 * w_:
+            raise ValueError(f"skip2 {tuple(skip2.shape)} does not upsample to [{B}, {2 * h}, {2 * w_}]")
+    # input channels of every convolution of the block, as the concat-free wiring assumes them
+    want = {"up": (1, concat.shape[3], Cin), "sup": (1, Cin, C), "aspp_up": (3, Cin, C), "aspp_up2": (3, 2 * C, C),
+            "skip": (1, skip_feat.shape[3], C) if use_skip else (3, 2 * C, C), "out": (1, nsl * C, C)}
+    if use_skip2:
+        want["skip2"] = (1, skip2.shape[3], C)
+    flat, extras = [], {}
+    for nm in names:
+        q = params[nm]
+        vecs = [q["gamma"], q["beta"]]
+        if nm != "skip_bn":
+            k, ci, cv = want[nm]
+            wt = _check(q["w"], f"{nm}.w", 4)
+            if tuple(wt.shape) != (k, k, ci, cv):
+                raise ValueError(f"{nm}.w must be [{k}, {k}, {ci}, {cv}], got {tuple(wt.shape)}")
+        else:
+            cv = skip_feat.shape[3]
+        tensors = {"gamma": vecs[0], "beta": vecs[1], "moving_mean": q.get("moving_mean"), "moving_var": q.get("moving_var")}
+        for key, v in tensors.items():
+            if v is not None:
+                _check(v, f"{nm}.{key}", 1, cv)
+        for key, v in {**tensors, **({"w": q["w"]} if nm != "skip_bn" else {})}.items():
+            if v is not None and not v.is_contiguous():
+                raise ValueError(f"{nm}.{key} must be contiguous (its gradient / update is written in place)")
+        _same_device(concat, *([q["w"]] if nm != "skip_bn" else []), *tensors.values())
+        flat += vecs if nm == "skip_bn" else [q["w"], *vecs]
+        extras[nm] = {k: q[k] for k in ("moving_mean", "moving_var") if q.get(k) is not None}
+    cfg = (tuple(names), tuple(int(r) for r in rates), bool(use_skip), bool(use_skip2), extras)
+    return _DenseLevel.apply(cfg, concat, skip_feat if use_skip else None, skip2 if use_skip2 else None, *flat)
+
+
 def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None, rates=(2, 4), use_skip: bool = True,
-                          use_skip2: bool = True, skip2: Tensor = None, process_group=None):
+                          use_skip2: bool = True, skip2: Tensor = None, process_group=None, fused_level: bool = True):
     """``nets.disp_bottleneck_dense`` (nets.py:451-471), one decoder level of ``disp_aspp_u_dense``, every op a
     hand-written kernel: x2 bilinear upsample, 1x1 and dilated 3x3 convolutions on fp32 MFMA, batch norm (training) +
-    ELU; ``torch.cat`` only moves data.  ``params``: name -> dict(w, gamma, beta[, moving_mean, moving_var]) for
+    ELU.  ``fused_level`` (default; single-rank statistics only): the level is ONE autograd node that never materialises
+    a concat - the batch norms write channel slices of one buffer, the convolutions read slices of it, the backward sums
+    the gradients of an activation's several readers while loading them (``_DenseLevel``); False, or a ``process_group``:
+    the operators composed through autograd with ``torch.cat``.  ``params``: name -> dict(w, gamma, beta[, moving_mean, moving_var]) for
     'up' (:455), 'sup' (:456), 'aspp_up' (:457), 'aspp_up2' (:458), 'skip' (:461 or :463), ['skip2' (:466)], 'out'
     (:470) and, with use_skip, 'skip_bn' = dict(gamma, beta, ...) for the batch norm of the skip feature (:460).
     ``skip_feat`` = end_points[skip_block].  Returns (xconcat, upnet) like the reference.  ``process_group``: every
     batch norm of the block takes its statistics over all ranks of the group (see ``batch_norm_elu``)."""
     from .pyramid import resize_bilinear
     import functools
+    import os
+    if process_group is None and fused_level and os.environ.get("SFM_LEVEL_FUSED", "1") != "0":
+        return _dense_level(params, concat, skip_feat, rates, use_skip, use_skip2, skip2)
     conv = functools.partial(_slim_conv, process_group=process_group)
     h, w = concat.shape[1], concat.shape[2]
     upnet = resize_bilinear(concat, 2 * h, 2 * w)                                        # :454

@@ -141,7 +141,8 @@ template <int BM, int BN, int WM, int WN, bool EP, int STAGES = 2>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 + (STAGES == 3 ? 256 : (BM / WM) * (BN / WN) * 64))
 __attribute__((amdgpu_waves_per_eu(STAGES == 3 ? 3 : 4, STAGES == 3 ? 3 : 4)))
 void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out,
-                         float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps, Epilogue ep) {
+                         float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps, Epilogue ep,
+                         int lda) {  // lda: floats between the rows of `in` (Cin, or more when `in` is a channel slice)
   constexpr int NW = (BM / WM) * (BN / WN), NL = STAGES == 3 ? 4 : NW;  // multiplier waves, loader waves
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN;
@@ -226,7 +227,7 @@ void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__
             }
           }
           vmask[q] = mask;
-          aoff[q] = ((m0 + row) * Cin + kg4) * 4;
+          aoff[q] = ((m0 + row) * lda + kg4) * 4;
           x += 8;  // the next instruction's row: 8 pixels on
           while (x >= W) { x -= W; ++y; }
           while (y >= H) y -= H;
@@ -235,7 +236,7 @@ void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__
       auto issue = [&](int g, float* As) __attribute__((always_inline)) {  // K-step g of the tile -> tile buffer As
         const int tap = g / csteps, c0 = (g - tap * csteps) * BK;
         const int dy = (tap / 3 - 1) * rate, dx = (tap % 3 - 1) * rate;
-        const char* abase = reinterpret_cast<const char*>(in) + ((long)(dy * W + dx) * Cin + c0) * 4;  // uniform
+        const char* abase = reinterpret_cast<const char*>(in) + ((long)(dy * W + dx) * lda + c0) * 4;  // uniform
         const char* bbase = reinterpret_cast<const char*>(wt) + (((long)tap * Cin + c0) * Cout + n0) * 4;
 #pragma unroll
         for (int q = 0; q < A_IT; ++q) {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __re
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(conv_threads(BM, BN, WM, WN)) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void aspp_wgrad_sk_kernel(const float* __restrict__ in, const float* __restrict__ gout, float* __restrict__ gw,
-                          float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps) {
+                          float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps, int lda) {
   constexpr int NW = (BM / WM) * (BN / WN), NL = NW;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BN;
@@ -513,7 +514,7 @@ void aspp_wgrad_sk_kernel(const float* __restrict__ in, const float* __restrict_
     for (int q = 0; q < A_IT; ++q) {
       const int f = (wave * A_IT + q) * 256 + lane * 4;
       ak[q] = f / BM;
-      aoff[q] = (ak[q] * Cin + f % BM) * 4;
+      aoff[q] = (ak[q] * lda + f % BM) * 4;
     }
 #pragma unroll
     for (int q = 0; q < B_IT; ++q) {
@@ -538,10 +539,10 @@ void aspp_wgrad_sk_kernel(const float* __restrict__ in, const float* __restrict_
         ay[q] = (int)(rem / (unsigned)W);
         ax[q] = (int)(rem - (unsigned)ay[q] * (unsigned)W);
       }
-      const char* abase0 = reinterpret_cast<const char*>(in) + ((long)(dy * W + dx) * Cin + ci0) * 4;
+      const char* abase0 = reinterpret_cast<const char*>(in) + ((long)(dy * W + dx) * lda + ci0) * 4;
       const char* bbase0 = reinterpret_cast<const char*>(gout) + (long)co0 * 4;
       auto issue = [&](int g, float* As) __attribute__((always_inline)) {  // K-step g -> tile buffer As
-        const char* abase = abase0 + (long)g * BK * Cin * 4;
+        const char* abase = abase0 + (long)g * BK * lda * 4;
         const char* bbase = bbase0 + (long)g * BK * Cout * 4;
         const long left = M - (long)g * BK;  // pixels from the step's first one to the end
 #pragma unroll
@@ -622,7 +623,7 @@ void aspp_wgrad_sk_kernel(const float* __restrict__ in, const float* __restrict_
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
     const float* __restrict__ in, const float* __restrict__ gout, float* __restrict__ gw, int B, int H, int W, int Cin,
-    int Cout, int rate, long pps) {
+    int Cout, int rate, long pps, int lda) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int A_IT = BK * BM / 4 / NT, B_IT = BK * BN / 4 / NT;
@@ -660,7 +661,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
       ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int y = ay[it] + dy, x = ax[it] + dx;
       if (pstep + k < p1 && y >= 0 && y < H && x >= 0 && x < W)
-        ra[it] = *reinterpret_cast<const float4*>(in + (ab[it] + (long)y * W + x) * Cin + ci0 + c4 * 4);
+        ra[it] = *reinterpret_cast<const float4*>(in + (ab[it] + (long)y * W + x) * lda + ci0 + c4 * 4);
       ax[it] += BK;  // next K-step
       while (ax[it] >= W) { ax[it] -= W; ++ay[it]; }
       while (ay[it] >= H) { ay[it] -= H; ab[it] += (long)H * W; }
@@ -717,7 +718,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void aspp_wgrad_kernel(
 constexpr int kSegMaxRate = 16;
 __global__ __launch_bounds__(384, 2) void aspp_wgrad9_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                           float* __restrict__ gw, int B, int H, int W, int Cin, int Cout,
-                                                          int rate, long sps) {
+                                                          int rate, long sps, int lda) {
   constexpr int BM = 64, BN = 32, LDA = BM + 4, LDB = BN + 4, NT = 384;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int PW = BK + 2 * rate;              // patch width in pixels
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(384, 2) void aspp_wgrad9_kernel(const float* __rest
       const int yy = y + (pr - 1) * rate, xx = xs - rate + px;
       ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < na4 && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        ra[it] = *reinterpret_cast<const float4*>(in + ((rbase + yy) * W + xx) * Cin + ci0 + c4 * 4);
+        ra[it] = *reinterpret_cast<const float4*>(in + ((rbase + yy) * W + xx) * lda + ci0 + c4 * 4);
     }
 #pragma unroll
     for (int it = 0; it < kBIt; ++it) {
@@ -948,8 +949,9 @@ static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
 // ntaps = 9: the dilated 3x3; ntaps = 1: a 1x1 convolution = the same kernels on the centre tap alone (rate 0 makes every
 // tap offset zero, the weights are [1][Cin][Cout]).
 static int launch_conv(const float* in, const float* wt, float* out, float* slabs, int B, int H, int W, int Cin, int Cout,
-                       int rate, hipStream_t stream, int ntaps = 9, Epilogue ep = Epilogue{nullptr, nullptr, 0}) {
+                       int rate, hipStream_t stream, int ntaps = 9, Epilogue ep = Epilogue{nullptr, nullptr, 0}, int lda = 0) {
   const long M = (long)B * H * W;
+  if (lda == 0) lda = Cin;
   const ConvPlan p = conv_plan(M, Cin, Cout, ntaps);
   if (ntaps == 1) rate = 0;
   const int K = ntaps * (Cin / BK);
@@ -958,10 +960,10 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
   do {                                                                                                                  \
     if (ep.scale)                                                                                                       \
       hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, true, ST_>), dim3((unsigned)p.nwg), dim3(NT_), 0, stream, in, wt, \
-                         out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                              \
+                         out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep, lda);                                         \
     else                                                                                                                \
       hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false, ST_>), dim3((unsigned)p.nwg), dim3(NT_), 0, stream, in,    \
-                         wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep);                                          \
+                         wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep, lda);                                     \
     hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, false, false>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
                        0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, 1, ep);                                     \
   } while (0)
@@ -1021,6 +1023,19 @@ extern "C" int sfm_aspp_conv3x3_fwd(const float* in, const float* w, int B, int 
   return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, rate, (hipStream_t)stream);
 }
 
+// The same with `in` a CHANNEL SLICE of a wider NHWC buffer: in points at the slice's first channel of pixel 0, ld_in =
+// floats between consecutive pixels (the buffer's channel count).  What the concat-free decoder level reads:
+// tf.concat([supnet, aspp_up], 3) (nets.py:458) is the first 2C channels of the level's one concat buffer.
+static bool slice_ok(const float* in, int ld_in, int Cin, long M) {
+  return ld_in >= Cin && ld_in % 4 == 0 && ((uintptr_t)in & 15) == 0 && M * ld_in < (1L << 40);
+}
+extern "C" int sfm_aspp_conv3x3_fwd_ld(const float* in, int ld_in, const float* w, int B, int H, int W, int Cin, int Cout,
+                                       int rate, float* out, float* ws, void* stream) {
+  if (!in || !w || !out || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate) || !slice_ok(in, ld_in, Cin, (long)B * H * W))
+    return SFM_ERR_ARG;
+  return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, rate, (hipStream_t)stream, 9, Epilogue{nullptr, nullptr, 0}, ld_in);
+}
+
 // slim.conv2d(in, Cout, [3, 3], rate=rate) under the arg-scope with is_training=False (the inference graphs,
 // test_kitti_depth_con.py:19-65): convolution, batch norm on the MOVING statistics, ELU (act != 0) - one pass, the
 // normalisation and activation applied where the MFMA kernel (or its slab reduction) stores the finished sums.
@@ -1050,15 +1065,16 @@ extern "C" int sfm_aspp_conv3x3_bwd_data(const float* gout, const float* w, int 
 }
 
 static int launch_wgrad(const float* in, const float* gout, int B, int H, int W, int Cin, int Cout, int rate, float* gw,
-                        float* ws, hipStream_t stream, int ntaps) {
+                        float* ws, hipStream_t stream, int ntaps, int lda = 0) {
   if (ntaps == 1) rate = 0;
+  if (lda == 0) lda = Cin;
   const WgradPlan p = wgrad_plan(B, H, W, Cin, Cout, rate, ntaps);
   float* dst = p.splits > 1 ? ws : gw;  // (stream-K plans: splits = 0, the slabs live in ws)
   const dim3 grid((Cin / p.bm) * (Cout / p.bn), ntaps, p.splits);
   if (p.cfg == 4) {
     const size_t lds = (size_t)(3 * (BK + 2 * rate) * 68 + BK * 36) * sizeof(float);
     hipLaunchKernelGGL(aspp_wgrad9_kernel, dim3((Cin / 64) * (Cout / 32), p.splits), dim3(384), lds, stream, in, gout, dst, B, H,
-                       W, Cin, Cout, rate, p.pps);
+                       W, Cin, Cout, rate, p.pps, lda);
   } else if (p.cfg == 0 || p.cfg == 1) {
     const long M = (long)B * H * W;
     const int K = (int)((M + BK - 1) / BK);
@@ -1068,7 +1084,7 @@ static int launch_wgrad(const float* in, const float* gout, int B, int H, int W,
 #define SFM_WGRAD_LAUNCH(BM_, BN_, WM_, WN_)                                                                                  \
   do {                                                                                                                        \
     hipLaunchKernelGGL((aspp_wgrad_sk_kernel<BM_, BN_, WM_, WN_>), dim3((unsigned)p.pps), dim3(conv_threads(BM_, BN_, WM_, WN_)), \
-                       0, stream, in, gout, gw, ws, B, H, W, Cin, Cout, rate, ntaps);                                         \
+                       0, stream, in, gout, gw, ws, B, H, W, Cin, Cout, rate, ntaps, lda);                                    \
     if (wide)                                                                                                                 \
       hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, true, true>), dim3((unsigned)tiles, BM_ * BN_ / 4 / 16), dim3(kBlock),  \
                          0, stream, ws, gw, (long)Cin, Cout, K, p.pps, tiles * K, ntaps, none);                               \
@@ -1084,10 +1100,10 @@ static int launch_wgrad(const float* in, const float* gout, int B, int H, int W,
     return sfm_last_error();
   } else if (p.cfg == 2)
     hipLaunchKernelGGL((aspp_wgrad_kernel<64, 32, 32, 32>), grid, dim3(128), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
-                       rate, p.pps);
+                       rate, p.pps, lda);
   else
     hipLaunchKernelGGL((aspp_wgrad_kernel<32, 32, 32, 32>), grid, dim3(64), 0, stream, in, gout, dst, B, H, W, Cin, Cout,
-                       rate, p.pps);
+                       rate, p.pps, lda);
   if (p.splits > 1) {
     const long n4 = (long)ntaps * Cin * Cout / 4;
     launch_reduce(ws, n4, p.splits, gw, stream);
@@ -1100,6 +1116,14 @@ extern "C" int sfm_aspp_conv3x3_bwd_weight(const float* in, const float* gout, i
                                            int rate, float* gw, float* ws, void* stream_) {
   if (!in || !gout || !gw || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate)) return SFM_ERR_ARG;
   return launch_wgrad(in, gout, B, H, W, Cin, Cout, rate, gw, ws, (hipStream_t)stream_, 9);
+}
+
+// dL/d w with `in` a channel slice (see sfm_aspp_conv3x3_fwd_ld)
+extern "C" int sfm_aspp_conv3x3_bwd_weight_ld(const float* in, int ld_in, const float* gout, int B, int H, int W, int Cin,
+                                              int Cout, int rate, float* gw, float* ws, void* stream_) {
+  if (!in || !gout || !gw || !ws || !conv_dims_ok(B, H, W, Cin, Cout, rate) || !slice_ok(in, ld_in, Cin, (long)B * H * W))
+    return SFM_ERR_ARG;
+  return launch_wgrad(in, gout, B, H, W, Cin, Cout, rate, gw, ws, (hipStream_t)stream_, 9, ld_in);
 }
 
 // ---- 1x1 convolutions of the same block (nets.py:455, 456, 461, 466, 470): slim.conv2d(x, Cout, [1, 1]) itself, NHWC x

@@ -47,12 +47,28 @@ static inline bool bn_plan(long M, int C, BnPlan& p) {
 
 __device__ __forceinline__ float elu_grad_from_y(float y) { return y < 0.0f ? y + 1.0f : 1.0f; }
 
+// dL/dy as the SUM of up to three tensors, each a channel slice of its own buffer (row stride ld floats): what the
+// concat-free decoder level hands over - a slice of the gradient of the concat buffer plus the input gradients of the
+// convolutions that read the same activation (nets.py:458, 463, 467) - without a pass that adds them up first.
+struct GySrc {
+  const float* p[3];
+  int ld[3];
+  int n;
+};
+__device__ __forceinline__ float4 gy_load(const GySrc& s, long row, int g) {
+  float4 v = *reinterpret_cast<const float4*>(s.p[0] + row * s.ld[0] + 4 * g);
+  for (int k = 1; k < s.n; ++k) {  // uniform
+    const float4 u = *reinterpret_cast<const float4*>(s.p[k] + row * s.ld[k] + 4 * g);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  return v;
+}
+
 // part [chunks][2][C] (fp64): MODE 0: (sum x, sum x^2 about `shift`);  MODE 1: (sum dz, sum dz xhat)
 // The forward sums are taken about a per-channel shift (the channel's first row) so that E[d^2] - E[d]^2 does not cancel.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ gy,
-                                                            const float* __restrict__ mean,
+__global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y, int ldy,
+                                                            GySrc gy, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, long M, int C, BnPlan p,
                                                             int act, double* __restrict__ part) {
   __shared__ double red[kBlock][8];
@@ -75,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const float* __restr
       a[0] += d0; a[1] += d1; a[2] += d2; a[3] += d3;
       b[0] += (double)d0 * d0; b[1] += (double)d1 * d1; b[2] += (double)d2 * d2; b[3] += (double)d3 * d3;
     } else {
-      const float4 yv = *reinterpret_cast<const float4*>(y + o), gv = *reinterpret_cast<const float4*>(gy + o);
+      const float4 yv = *reinterpret_cast<const float4*>(y + (size_t)r * ldy + 4 * g), gv = gy_load(gy, r, g);
       const float z0 = act ? gv.x * elu_grad_from_y(yv.x) : gv.x, z1 = act ? gv.y * elu_grad_from_y(yv.y) : gv.y;
       const float z2 = act ? gv.z * elu_grad_from_y(yv.z) : gv.z, z3 = act ? gv.w * elu_grad_from_y(yv.w) : gv.w;
       a[0] += z0; a[1] += z1; a[2] += z2; a[3] += z3;
@@ -191,10 +207,11 @@ __global__ __launch_bounds__(kBlock) void bn_elu_apply_kernel(const float* __res
                                                               const float* __restrict__ beta,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, long n4, int groups,
-                                                              int act, float* __restrict__ y) {
+                                                              int act, float* __restrict__ y, int ldy) {
   const long e = (long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= n4) return;
-  const int g = (int)(e % groups);
+  const long row = e / groups;
+  const int g = (int)(e - row * groups);
   const float4 xv = reinterpret_cast<const float4*>(x)[e];
   const float4 ga = reinterpret_cast<const float4*>(gamma)[g], be = reinterpret_cast<const float4*>(beta)[g];
   const float4 m = reinterpret_cast<const float4*>(mean)[g], is = reinterpret_cast<const float4*>(invstd)[g];
@@ -204,12 +221,11 @@ __global__ __launch_bounds__(kBlock) void bn_elu_apply_kernel(const float* __res
   o.z = ga.z * ((xv.z - m.z) * is.z) + be.z;
   o.w = ga.w * ((xv.w - m.w) * is.w) + be.w;
   if (act) { o.x = elu(o.x); o.y = elu(o.y); o.z = elu(o.z); o.w = elu(o.w); }
-  reinterpret_cast<float4*>(y)[e] = o;
+  *reinterpret_cast<float4*>(y + row * ldy + 4 * g) = o;  // ldy = C: y is a tensor of its own; more: a slice of the concat buffer
 }
 
 __global__ __launch_bounds__(kBlock) void bn_elu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                                  const float* __restrict__ gy,
-                                                                  const float* __restrict__ gamma,
+                                                                  int ldy, GySrc gy, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd,
                                                                   const float* __restrict__ ggamma,
@@ -217,9 +233,10 @@ __global__ __launch_bounds__(kBlock) void bn_elu_bwd_apply_kernel(const float* _
                                                                   float inv_m, int act, float* __restrict__ gx) {
   const long e = (long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= n4) return;
-  const int g = (int)(e % groups);
-  const float4 xv = reinterpret_cast<const float4*>(x)[e], yv = reinterpret_cast<const float4*>(y)[e];
-  const float4 gv = reinterpret_cast<const float4*>(gy)[e];
+  const long row = e / groups;
+  const int g = (int)(e - row * groups);
+  const float4 xv = reinterpret_cast<const float4*>(x)[e], yv = *reinterpret_cast<const float4*>(y + row * ldy + 4 * g);
+  const float4 gv = gy_load(gy, row, g);
   const float4 ga = reinterpret_cast<const float4*>(gamma)[g];
   const float4 m = reinterpret_cast<const float4*>(mean)[g], is = reinterpret_cast<const float4*>(invstd)[g];
   const float4 gg = reinterpret_cast<const float4*>(ggamma)[g], gb = reinterpret_cast<const float4*>(gbeta)[g];
@@ -248,42 +265,67 @@ extern "C" long long sfm_bn_elu_workspace_floats(long long M, int C) {
   return (long long)p.chunks * 2 * C * 2 + 4;
 }
 
-extern "C" int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* beta, long long M, int C, float eps, double decay,
-                              int act, float* moving_mean, float* moving_var, float* y, float* save_mean,
-                              float* save_invstd, float* ws, void* stream_) {
+static bool slice_ok(const float* q, int ld, int C) { return q && ld >= C && ld % 4 == 0 && ((uintptr_t)q & 15) == 0; }
+
+// y may be a channel slice of a wider [M, ld_y] buffer (the level's concat buffer): ld_y floats between its rows
+extern "C" int sfm_bn_elu_fwd_ld(const float* x, const float* gamma, const float* beta, long long M, int C, float eps,
+                                 double decay, int act, float* moving_mean, float* moving_var, float* y, int ld_y,
+                                 float* save_mean, float* save_invstd, float* ws, void* stream_) {
   BnPlan p;
-  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || !bn_plan((long)M, C, p) || !(eps > 0.0f))
+  if (!x || !gamma || !beta || !slice_ok(y, ld_y, C) || !save_mean || !save_invstd || !ws || !bn_plan((long)M, C, p) ||
+      !(eps > 0.0f))
     return SFM_ERR_ARG;
   if (((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;  // fp64 partials
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, (const float*)nullptr, 0, GySrc{},
+                     (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, x, (long)M, C,
                      p.chunks, eps, (float)(1.0 - decay), moving_mean, moving_var, save_mean, save_invstd);
   const long n4 = (long)M * p.groups;
   hipLaunchKernelGGL(bn_elu_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, gamma, beta,
-                     save_mean, save_invstd, n4, p.groups, act, y);
+                     save_mean, save_invstd, n4, p.groups, act, y, ld_y);
+  return sfm_last_error();
+}
+
+extern "C" int sfm_bn_elu_fwd(const float* x, const float* gamma, const float* beta, long long M, int C, float eps, double decay,
+                              int act, float* moving_mean, float* moving_var, float* y, float* save_mean,
+                              float* save_invstd, float* ws, void* stream_) {
+  return sfm_bn_elu_fwd_ld(x, gamma, beta, M, C, eps, decay, act, moving_mean, moving_var, y, C, save_mean, save_invstd, ws, stream_);
+}
+
+// y a channel slice ([M, ld_y] buffer); dL/dy = gy[0] + ... + gy[n_gy - 1], each a channel slice with its own row stride
+extern "C" int sfm_bn_elu_bwd_ld(const float* x, const float* y, int ld_y, const float* const* gy, const int* ld_gy, int n_gy,
+                                 const float* gamma, const float* save_mean, const float* save_invstd, long long M, int C,
+                                 int act, float* gx, float* ggamma, float* gbeta, float* ws, void* stream_) {
+  BnPlan p;
+  if (!x || !slice_ok(y, ld_y, C) || !gy || !ld_gy || n_gy < 1 || n_gy > 3 || !gamma || !save_mean || !save_invstd || !gx ||
+      !ggamma || !gbeta || !ws || !bn_plan((long)M, C, p))
+    return SFM_ERR_ARG;
+  if (((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;
+  GySrc src{};
+  src.n = n_gy;
+  for (int k = 0; k < n_gy; ++k) {
+    if (!slice_ok(gy[k], ld_gy[k], C)) return SFM_ERR_ARG;
+    src.p[k] = gy[k];
+    src.ld[k] = ld_gy[k];
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, y, ld_y, src, save_mean, save_invstd,
+                     (long)M, C, p, act, part);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma,
+                     gbeta);
+  const long n4 = (long)M * p.groups;
+  hipLaunchKernelGGL(bn_elu_bwd_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, y, ld_y, src,
+                     gamma, save_mean, save_invstd, ggamma, gbeta, n4, p.groups, (float)(1.0 / (double)M), act, gx);
   return sfm_last_error();
 }
 
 extern "C" int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
                               const float* save_invstd, long long M, int C, int act, float* gx, float* ggamma,
                               float* gbeta, float* ws, void* stream_) {
-  BnPlan p;
-  if (!x || !y || !gy || !gamma || !save_mean || !save_invstd || !gx || !ggamma || !gbeta || !ws || !bn_plan((long)M, C, p))
-    return SFM_ERR_ARG;
-  if (((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
-                     p, act, part);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma,
-                     gbeta);
-  const long n4 = (long)M * p.groups;
-  hipLaunchKernelGGL(bn_elu_bwd_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, y, gy,
-                     gamma, save_mean, save_invstd, ggamma, gbeta, n4, p.groups, (float)(1.0 / (double)M), act, gx);
-  return sfm_last_error();
+  return sfm_bn_elu_bwd_ld(x, y, C, &gy, &C, 1, gamma, save_mean, save_invstd, M, C, act, gx, ggamma, gbeta, ws, stream_);
 }
 
 // ---- the same batch norm with statistics over ALL ranks of a data-parallel job (no counterpart in the reference, which is
@@ -296,8 +338,8 @@ extern "C" int sfm_bn_local_stats(const float* x, long long M, int C, double* st
   if (!x || !stats || !ws || !bn_plan((long)M, C, p) || ((uintptr_t)ws & 7) != 0) return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, (const float*)nullptr, 0, GySrc{},
+                     (const float*)nullptr, (const float*)nullptr, (long)M, C, p, 0, part);
   hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, x, (long)M, C, p.chunks, stats);
   return sfm_last_error();
 }
@@ -315,7 +357,7 @@ extern "C" int sfm_bn_elu_apply_stats(const float* x, const float* gamma, const 
                      (float)(1.0 - decay), moving_mean, moving_var, save_mean, save_invstd);
   const long n4 = (long)M * p.groups;
   hipLaunchKernelGGL(bn_elu_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, gamma, beta,
-                     save_mean, save_invstd, n4, p.groups, act, y);
+                     save_mean, save_invstd, n4, p.groups, act, y, C);
   return sfm_last_error();
 }
 
@@ -329,8 +371,10 @@ extern "C" int sfm_bn_elu_bwd_sums(const float* x, const float* y, const float* 
     return SFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, y, gy, save_mean, save_invstd, (long)M, C,
-                     p, act, part);
+  GySrc src{};
+  src.n = 1; src.p[0] = gy; src.ld[0] = C;
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.chunks, p.slabs), dim3(kBlock), 0, stream, x, y, C, src, save_mean, save_invstd,
+                     (long)M, C, p, act, part);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kBlock), 0, stream, part, C, p.chunks, ggamma, gbeta);
   return sfm_last_error();
 }
@@ -344,8 +388,10 @@ extern "C" int sfm_bn_elu_bwd_apply(const float* x, const float* y, const float*
       !bn_plan((long)M, C, p))
     return SFM_ERR_ARG;
   const long n4 = (long)M * p.groups;
+  GySrc src{};
+  src.n = 1; src.p[0] = gy; src.ld[0] = C;
   hipLaunchKernelGGL(bn_elu_bwd_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
-                     x, y, gy, gamma, save_mean, save_invstd, ggamma_all, gbeta_all, n4, p.groups,
+                     x, y, C, src, gamma, save_mean, save_invstd, ggamma_all, gbeta_all, n4, p.groups,
                      (float)(1.0 / (double)M_global), act, gx);
   return sfm_last_error();
 }

@@ -284,6 +284,44 @@ def test_disp_bottleneck_dense_block(dev, cin, cout, rates, use_skip, use_skip2)
         assert rel_err(a.grad, b.grad) <= 2e-4
 
 
+@pytest.mark.parametrize("cin,cout,rates,use_skip,use_skip2", [
+    (128, 64, (2, 4), True, False), (64, 32, (3, 6), True, True), (64, 32, (3, 6), False, True)])
+def test_concat_free_level_equals_the_composed_operators(dev, cin, cout, rates, use_skip, use_skip2):
+    """the level as one autograd node (batch norms writing channel slices of one buffer, convolutions reading slices,
+    gradients of an activation's several readers summed while loading) against the same operators composed through
+    autograd with torch.cat: outputs, and the gradient of EVERY input and parameter (gamma / beta included), the upnet
+    output used downstream in one run and unused in the other"""
+    g = torch.Generator().manual_seed(21)
+    B, h, w = 2, 5, 9
+    base = dict(concat=torch.randn(B, h, w, cin, generator=g),
+                skip_feat=torch.randn(B, 2 * h, 2 * w, 96, generator=g) if use_skip else None,
+                skip2=torch.randn(B, h - 1, w - 2, cin, generator=g) if use_skip2 else None)   # (any size that upsamples)
+    p = _block_params(g, cin, cout, 96, use_skip, use_skip2, cin)
+    wy, wu = torch.randn(B, 2 * h, 2 * w, cout, generator=g).to(dev), torch.randn(B, 2 * h, 2 * w, cin, generator=g).to(dev)
+    for use_upnet in (True, False):
+        runs = []
+        for fused in (True, False):
+            inp = {k: (None if v is None else v.to(dev).requires_grad_(True)) for k, v in base.items()}
+            pg = {k: {kk: vv.to(dev).requires_grad_(True) for kk, vv in v.items()} for k, v in p.items()}
+            for q in pg.values():   # moving statistics, updated in place by both forms
+                c = q["gamma"].shape[0]
+                q["moving_mean"], q["moving_var"] = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            y, u = sfm_amd.disp_bottleneck_dense(pg, inp["concat"], inp["skip_feat"], rates, use_skip, use_skip2, inp["skip2"],
+                                                 fused_level=fused)
+            ((y * wy).sum() + ((u * wu).sum() if use_upnet else 0.0)).backward()
+            leaves = {f"in.{k}": v for k, v in inp.items() if v is not None}
+            leaves.update({f"{k}.{kk}": vv for k, v in pg.items() for kk, vv in v.items()})
+            runs.append((y.detach(), u.detach(), leaves))
+        (yf, uf, lf), (yc, uc, lc) = runs
+        assert torch.equal(yf, yc) and torch.equal(uf, uc)          # the same kernels in the same order
+        for name in lf:
+            if name.endswith("moving_mean") or name.endswith("moving_var"):
+                assert torch.equal(lf[name], lc[name]), name
+                continue
+            assert lf[name].grad is not None, name
+            assert rel_err(lf[name].grad, lc[name].grad) <= 2e-6, (name, use_upnet)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,rate,act", [
     (2, 8, 26, 256, 128, 2, True),     # small M: tiles cut by several stream-K ranges, epilogue in the fix-up kernel
     (2, 32, 52, 64, 32, 3, True),      # 256x32 tiles, epilogue in the MFMA kernel's store loop
