@@ -476,6 +476,40 @@ __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __re
   *reinterpret_cast<float4*>(out + orow * Cout + n0 + c4) = s;
 }
 
+// The same sums for the convolutions, launched over the BOUNDARIES between consecutive workgroups' ranges instead of over
+// the tiles: only a boundary that falls inside a tile cuts one (at most nwg - 1 tiles of up to thousands), and the first
+// boundary inside a tile handles it.  grid (nwg - 1, BM * BN / 4 / 256).  (The tile-indexed form spent 13-25 us per
+// convolution mostly on workgroups that found their tile uncut after a round of 64-bit divisions.)
+template <int BM, int BN>
+__global__ __launch_bounds__(kBlock) void aspp_sk_fixup_cut_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                   long M, int Cout, int K, long nwg, long total, Epilogue ep) {
+  const long b = blockIdx.x;  // the boundary between workgroups b and b + 1
+  const long u = sk_first_unit(b + 1, total, nwg);
+  const long t = u / K, ta = t * K, tb = ta + K;
+  if (u == ta || u >= total) return;               // a tile edge: nothing is cut here
+  if (sk_first_unit(b, total, nwg) > ta) return;   // workgroup b starts inside the same tile: an earlier boundary handles it
+  const int e = blockIdx.y * kBlock + threadIdx.x;  // float4 of the tile
+  const int row = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long w = b; w < nwg; ++w) {  // workgroup b holds the tile's first piece; pieces in workgroup order
+    const long a0 = sk_first_unit(w, total, nwg);
+    if (a0 >= tb) break;
+    const long seg0 = a0 > ta ? a0 : ta;
+    const float4 v = *reinterpret_cast<const float4*>(partial + ((w * 2 + (seg0 == a0 ? 0 : 1)) * (long)(BM * BN)) + (long)row * BN + c4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int ntn = Cout / BN;
+  const long tm = t / ntn, orow = tm * BM + row;
+  const int n0 = (int)(t - tm * ntn) * BN;
+  if (orow >= M) return;
+  if (ep.scale) {
+    const float4 sc = *reinterpret_cast<const float4*>(ep.scale + n0 + c4), sh = *reinterpret_cast<const float4*>(ep.shift + n0 + c4);
+    s = make_float4(ep_apply(s.x, sc.x, sh.x, ep.act), ep_apply(s.y, sc.y, sh.y, ep.act), ep_apply(s.z, sc.z, sh.z, ep.act),
+                    ep_apply(s.w, sc.w, sh.w, ep.act));
+  }
+  *reinterpret_cast<float4*>(out + orow * Cout + n0 + c4) = s;
+}
+
 // ------------------------------------------------------------------ backward weight, stream-K + LDS-DMA + loader waves
 // The same machinery for dL/dw[tap][ci][co] = sum_p in[p + tap offset][ci] * gout[p][co]: M = Cin, N = Cout, K = the
 // B*H*W pixels in steps of 32.  Both operands lie K-major in memory ([pixel][channel]), so both tiles are dense
@@ -964,8 +998,9 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
     else                                                                                                                \
       hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false, ST_>), dim3((unsigned)p.nwg), dim3(NT_), 0, stream, in,    \
                          wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep, lda);                                     \
-    hipLaunchKernelGGL((aspp_sk_fixup_kernel<BM_, BN_, false, false>), dim3((unsigned)tiles, BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
-                       0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, 1, ep);                                     \
+    if (p.nwg > 1)                                                                                                      \
+      hipLaunchKernelGGL((aspp_sk_fixup_cut_kernel<BM_, BN_>), dim3((unsigned)(p.nwg - 1), BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
+                         0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, ep);                                      \
   } while (0)
   if (p.cfg == 3)
     SFM_CONV_LAUNCH(256, 128, 64, 64, 3, 768);
