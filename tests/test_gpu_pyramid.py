@@ -102,7 +102,10 @@ def test_smooth_sign_at_exact_zero(dev):
     assert float(l.detach()) == 0.0 and float(x.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,sizes", [(2, [(16, 24), (8, 12)]), (3, [(128, 416), (64, 208), (32, 104), (16, 52)]), (1, [(5, 7)])])
+@pytest.mark.parametrize("B,sizes", [
+    (2, [(16, 24), (8, 12)]), (3, [(128, 416), (64, 208), (32, 104), (16, 52)]),   # one launch per direction
+    (1, [(5, 7)]), (2, [(16, 24), (7, 9)]),          # an item that is no multiple of 4 elements: the chunked launch pair
+    (1, [(192, 400), (96, 200)])])                   # an item beyond 64 Ki elements: the chunked launch pair
 def test_normalize_disp(dev, B, sizes):
     raw = [10.0 * torch.sigmoid(_rand((B, h, w, 1), 50 + k)) + 0.01 for k, (h, w) in enumerate(sizes)]
     gu = [_rand(r.shape, 60 + k) for k, r in enumerate(raw)]
@@ -117,6 +120,20 @@ def test_normalize_disp(dev, B, sizes):
         assert rel_err(dng[k], dno[k]) <= TOL_OUT
         assert rel_err(dpg[k], dpo[k]) <= TOL_OUT
         assert rel_err(rg[k].grad, ro[k].grad) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("use", ["disp_norm", "depth"])
+def test_normalize_disp_one_output_used(dev, use):
+    """only one of the two outputs reaches the loss: the other's gradient is absent (a null source in the kernels)"""
+    raw = [10.0 * torch.sigmoid(_rand((2, h, w, 1), 90 + k)) + 0.01 for k, (h, w) in enumerate([(32, 104), (16, 52)])]
+    g = [_rand(r.shape, 95 + k) for k, r in enumerate(raw)]
+    ro = [r.clone().requires_grad_(True) for r in raw]
+    rg = [r.to(dev).requires_grad_(True) for r in raw]
+    k = 0 if use == "disp_norm" else 1
+    sum((a * w).sum() for a, w in zip(R.normalize_disp(ro)[k], g)).backward()
+    sum((a * w.to(dev)).sum() for a, w in zip(sfm_amd.normalize_disp(rg)[k], g)).backward()
+    for a, b_ in zip(rg, ro):
+        assert rel_err(a.grad, b_.grad) <= TOL_GRAD
 
 
 def test_total_loss_from_raw_network_outputs(dev):
