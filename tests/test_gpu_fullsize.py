@@ -1,6 +1,8 @@
-"""BASELINE.json's full sizes, where the CPU oracle would take minutes: size-independent
-properties of the HIP path instead (the oracle comparisons at small sizes are in
-test_gpu_warp.py / test_gpu_loss.py / test_gpu_golden.py).
+"""BASELINE.json's full per-GPU BATCHES (up to 16 x 384 x 1248 and 8 x 1024 x 2048 x 4 sources), where the CPU oracle's
+autograd would need minutes and tens of GB: size-independent properties of the HIP path instead.  (The oracle comparisons
+are in test_gpu_warp.py / test_gpu_loss.py / test_gpu_golden.py - since round 3 including configs[1] at its full
+8 x 128 x 416 batch, the 8-GPU shard of configs[2] (4 x 384 x 1248, four scales) and one full 2048 x 1024 seq = 5 snippet
+of configs[3].)
 
   * two independent HIP implementations agree: the fused pipeline (csrc/loss.hip, loss_stencil.hip:
     separable sliding-window SSIM) and the reference's op-by-op decomposition (stand-alone operators

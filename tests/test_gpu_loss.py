@@ -42,6 +42,9 @@ def _gpu(inp, dev, fused, smooth_weight=0.0):
     (1, 128, 416, 4, 2, 0.01, True),   # one KITTI snippet, 4 scales
     (1, 384, 1248, 1, 2, 0.01, True),  # one full-resolution KITTI snippet (configs[2] image size): beyond one strip chunk
                                        # per wave, 20 x 12 splat tiles, the longest rows the oracle affords in seconds
+    (8, 128, 416, 4, 2, 0.01, True),   # configs[1] at its FULL per-GPU size against the oracle (the GPU box's host cores
+                                       # run the oracle's forward + backward at this size in about a second)
+    (4, 384, 1248, 4, 2, 0.01, True),  # configs[2]: the 8-GPU shard (B = 32 / 8) at full size, all four scales
 ])
 @pytest.mark.parametrize("fused", [True, False])
 def test_multi_scale_loss(dev, B, H, W, S, N, ps, full, fused):
@@ -64,8 +67,33 @@ def test_multi_scale_loss(dev, B, H, W, S, N, ps, full, fused):
             if amb is None or isinstance(amb, str):
                 ok, msg = grad_close(a, b, max_outlier_frac=0.0 if amb is None else 2e-3)
             else:
-                ok, msg = grad_close(a, b, max_outlier_frac=0.0, exclude=amb)
+                # strict below a million pixels; beyond, a handful of elements (4 of 11.5 M d_trans values fused, 9 of
+                # 1.9 M d_depth values unfused at configs[2]) sit behind one of the other discontinuities - sign(), == 0,
+                # floor - decided differently by two fp32 evaluation orders: grad_close's default allowance of 1e-5
+                ok, msg = grad_close(a, b, max_outlier_frac=0.0 if B * H * W < 1_000_000 else 1e-5, exclude=amb)
             assert ok, f"{name} scale {s}: {msg}"
+
+
+@pytest.mark.timeout(900)
+def test_config4_snippet_against_the_oracle(dev):
+    """configs[3] (2048 x 1024, seq = 5, Cityscapes intrinsics) at full image size against the oracle: one snippet, all
+    four scales and four sources - the overflow path of the splat (large parallax) and the second backward launch
+    (sources 2, 3) at the size they are meant for"""
+    B, H, W, S, N = 1, 1024, 2048, 4, 4
+    inp = synth.make_inputs(B, H, W, S=S, N=N, seed=33, pose_scale=0.01, full_res=True, cityscapes=True)
+    lo, do, po, to = _oracle(inp)
+    lg, dg, pg, tg = _gpu(inp, dev, True)
+    assert rel_err(lg, lo) <= TOL_OUT
+    assert rel_err(pg.grad, po.grad) <= 3 * TOL_GRAD   # (sums every pixel, the min-select-ambiguous ones included)
+    g = synth.to_device(inp, dev)
+    for s in range(S):
+        with torch.no_grad():
+            amb = min_select_ambiguous(g["tgt"], g["src"], g["K"], g["depth"][s].squeeze(3).contiguous(), g["pose"],
+                                       g["trans"][s].contiguous())
+        for name, a, b in (("d_depth", dg[s].grad, do[s].grad), ("d_trans", tg[s].grad, to[s].grad)):
+            ok, msg = grad_close(a, b, exclude=amb)
+            assert ok, f"{name} scale {s}: {msg}"
+    print(f"c4 snippet: loss rel err {rel_err(lg, lo):.2e}, d_pose rel err {rel_err(pg.grad, po.grad):.2e}")
 
 
 def test_loss_with_smoothness_terms(dev):
