@@ -624,6 +624,7 @@ def main() -> None:
     if wd.isdigit() and int(wd) > 0:
         import faulthandler
         faulthandler.dump_traceback_later(int(wd), exit=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (also when the driver's launcher started this rank directly)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
