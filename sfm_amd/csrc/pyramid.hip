@@ -567,33 +567,44 @@ __device__ __forceinline__ float smooth_element(const SmoothK& c, float p00, flo
   const float dy_m20 = qm1 - qm2, dy_m10 = p00 - qm1, dy_00 = qp1 - p00, dy_p10 = qp2 - qp1;
   const float dy_0m1 = dpm - pm1, dy_0p1 = dpp - pp1, dy_m1m1 = pm1 - dmm, dy_m1p1 = pp1 - dmp;
   const bool xa = xi <= wi - 2, xb = xi >= 1, ya = yi <= hi - 2, yb = yi >= 1;
-  float g = c.kab * sgnf(p00);
+  // The 19 signs as INTEGERS (one v_med3_i32 each on the float's bits: the samples are canonicalised on load, so no
+  // difference is -0.0), summed per coefficient and converted once: 2 compares + 2 selects + an FMA per sign term were
+  // two thirds of the kernel's instructions.
+  auto sg = [](float v) __attribute__((always_inline)) {
+    int r;  // (written as asm: the compiler turns max(min(bits, 1), -1) back into two compares and two selects)
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(v));
+    return r;
+  };
+  auto on = [](bool cnd, int v) __attribute__((always_inline)) { return cnd ? v : 0; };
   t[6] += fabsf(p00);
-  if (xa) { t[0] += fabsf(dx_00); g -= c.k1x * sgnf(dx_00); }
-  if (xb) g += c.k1x * sgnf(dx_0m1);
-  if (ya) { t[1] += fabsf(dy_00); g -= c.k1y * sgnf(dy_00); }
-  if (yb) g += c.k1y * sgnf(dy_m10);
-  if (xi <= wi - 3) { const float v = dx_0p1 - dx_00; t[2] += fabsf(v); g += c.k2xx * sgnf(v); }   // dx2 anchored at x
-  if (xb && xa) g -= 2.0f * c.k2xx * sgnf(dx_00 - dx_0m1);                                          // ... at x-1
-  if (xi >= 2) g += c.k2xx * sgnf(dx_0m1 - dx_0m2);                                                 // ... at x-2
-  if (yi <= hi - 3) { const float v = dy_p10 - dy_00; t[5] += fabsf(v); g += c.k2yy * sgnf(v); }    // dy2
-  if (yb && ya) g -= 2.0f * c.k2yy * sgnf(dy_00 - dy_m10);
-  if (yi >= 2) g += c.k2yy * sgnf(dy_m10 - dy_m20);
-  if (ya && xa) {  // dxdy = DX(y+1, x) - DX(y, x), dydx = DY(y, x+1) - DY(y, x): equal in exact arithmetic only
-    const float v1 = dx_p10 - dx_00, v2 = dy_0p1 - dy_00;
-    t[3] += fabsf(v1); t[4] += fabsf(v2);
-    g += c.k2xy * (sgnf(v1) + sgnf(v2));
-  }
-  if (ya && xb) g -= c.k2xy * (sgnf(dx_p1m1 - dx_0m1) + sgnf(dy_00 - dy_0m1));    // anchored at (y, x-1)
-  if (yb && xa) g -= c.k2xy * (sgnf(dx_00 - dx_m10) + sgnf(dy_m1p1 - dy_m10));    // anchored at (y-1, x)
-  if (yb && xb) g += c.k2xy * (sgnf(dx_0m1 - dx_m1m1) + sgnf(dy_m10 - dy_m1m1));  // anchored at (y-1, x-1)
+  if (xa) t[0] += fabsf(dx_00);
+  if (ya) t[1] += fabsf(dy_00);
+  const int n1x = on(xb, sg(dx_0m1)) - on(xa, sg(dx_00));
+  const int n1y = on(yb, sg(dy_m10)) - on(ya, sg(dy_00));
+  const float vxx = dx_0p1 - dx_00, vyy = dy_p10 - dy_00;   // dx2 / dy2 anchored at this element
+  if (xi <= wi - 3) t[2] += fabsf(vxx);
+  if (yi <= hi - 3) t[5] += fabsf(vyy);
+  const int nxx = on(xi <= wi - 3, sg(vxx)) - 2 * on(xb && xa, sg(dx_00 - dx_0m1)) + on(xi >= 2, sg(dx_0m1 - dx_0m2));
+  const int nyy = on(yi <= hi - 3, sg(vyy)) - 2 * on(yb && ya, sg(dy_00 - dy_m10)) + on(yi >= 2, sg(dy_m10 - dy_m20));
+  // dxdy = DX(y+1, x) - DX(y, x), dydx = DY(y, x+1) - DY(y, x): equal in exact arithmetic only
+  const float v1 = dx_p10 - dx_00, v2 = dy_0p1 - dy_00;
+  if (ya && xa) { t[3] += fabsf(v1); t[4] += fabsf(v2); }
+  const int nxy = on(ya && xa, sg(v1) + sg(v2))
+                - on(ya && xb, sg(dx_p1m1 - dx_0m1) + sg(dy_00 - dy_0m1))     // anchored at (y, x-1)
+                - on(yb && xa, sg(dx_00 - dx_m10) + sg(dy_m1p1 - dy_m10))     // anchored at (y-1, x)
+                + on(yb && xb, sg(dx_0m1 - dx_m1m1) + sg(dy_m10 - dy_m1m1));  // anchored at (y-1, x-1)
+  float g = c.kab * (float)sg(p00);
+  g += c.k1x * (float)n1x;
+  g += c.k1y * (float)n1y;
+  g += c.k2xx * (float)nxx;
+  g += c.k2yy * (float)nyy;
+  g += c.k2xy * (float)nxy;
   return g;
 }
 
 // One thread per RUN of kSmoothRun vertically adjacent pixels (x 3 channels when C is a multiple of 3); the lanes of a wave
 // are adjacent columns / channel groups (coalesced rows).  A run shares its samples: 8 + 6 + 6 + 4 + 4 = 28 loads for four
-// pixels instead of 4 x 13.  The kernel follows its VALU count (~140 instructions per element, 2 compares + 2 selects per
-// sign term): 30 -> 25 us for the c2 pyramid against ~15 us of pure issue time.  V = channels handled together.
+// pixels instead of 4 x 13.  The kernel follows its VALU count.  V = channels handled together.
 template <int V>
 __device__ __forceinline__ void smooth_run(const SmoothK& c, const float* __restrict__ img, float* __restrict__ gimg, int C,
                                            int ch, int xi, int y0, int wi, int hi, float gs, float* __restrict__ t) {
@@ -605,8 +616,9 @@ __device__ __forceinline__ void smooth_run(const SmoothK& c, const float* __rest
   for (int k = 0; k < 8; ++k) oy[k] = min(max(y0 + k - 2, 0), hi - 1) * sy;        // row y0 + k - 2
   float c0[8][V], cm1[6][V], cp1[6][V], cm2[4][V], cp2[4][V];
   auto ld = [&](float (&d)[V], int o) __attribute__((always_inline)) {
-    if constexpr (V == 3) { const f3 v = ld3(img + o); d[0] = v.x; d[1] = v.y; d[2] = v.z; }
-    else d[0] = img[o];
+    // (+ 0.0f: -0.0 -> +0.0, everything else unchanged - the integer sign of smooth_element reads the bits)
+    if constexpr (V == 3) { const f3 v = ld3(img + o); d[0] = v.x + 0.0f; d[1] = v.y + 0.0f; d[2] = v.z + 0.0f; }
+    else d[0] = img[o] + 0.0f;
   };
 #pragma unroll
   for (int k = 0; k < 8; ++k) ld(c0[k], oy[k] + ox[2]);

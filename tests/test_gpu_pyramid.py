@@ -102,6 +102,23 @@ def test_smooth_sign_at_exact_zero(dev):
     assert float(l.detach()) == 0.0 and float(x.grad.abs().max()) == 0.0
 
 
+def test_smooth_signs_with_negative_zero_samples(dev):
+    """the kernel takes the sign of a difference from the float's bits: -0.0 samples (and the -0.0 differences they could
+    produce next to +0.0 ones) must count as zero, as sign() does in the reference"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 9, 11, 3, generator=g)
+    x[torch.rand(x.shape, generator=g) < 0.3] = 0.0
+    x[torch.rand(x.shape, generator=g) < 0.3] = -0.0
+    xo = x.clone().requires_grad_(True)
+    lo = R.compute_smooth_loss(xo) + xo.abs().mean()
+    lo.backward()
+    xg = x.to(dev).requires_grad_(True)
+    lg = sfm_amd.compute_smooth_loss(xg) + xg.abs().mean()
+    lg.backward()
+    assert rel_err(lg, lo) <= TOL_OUT
+    assert rel_err(xg.grad, xo.grad) <= TOL_GRAD
+
+
 @pytest.mark.parametrize("B,sizes", [
     (2, [(16, 24), (8, 12)]), (3, [(128, 416), (64, 208), (32, 104), (16, 52)]),   # one launch per direction
     (1, [(5, 7)]), (2, [(16, 24), (7, 9)]),          # an item that is no multiple of 4 elements: the chunked launch pair
