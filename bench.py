@@ -280,14 +280,20 @@ def config5_leg(dev, reps: int = 10) -> dict:
         return loss
 
     def timed(with_loss):
-        for _ in range(6):   # (allocator pools, workspaces and clocks: the first measurement of a process read 20 % high with 3)
+        # allocator pools, workspaces and clocks: the first measurement of a process has read up to 25 % high (16.5 instead of
+        # 13.5 ms in some processes, whatever is timed first) - six warm-up steps, then the better of two timed rounds
+        for _ in range(6):
             step(with_loss)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            out = step(with_loss)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3, out
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = step(with_loss)
+            torch.cuda.synchronize()
+            ms_ = (time.perf_counter() - t0) / reps * 1e3
+            best = ms_ if best is None else min(best, ms_)
+        return best, out
 
     ms, loss = timed(True)
     ms_dec, _ = timed(False)
