@@ -297,11 +297,24 @@ def config5_leg(dev, reps: int = 10) -> dict:
 
     ms, loss = timed(True)
     ms_dec, _ = timed(False)
+    # the serving path: the same decoder under is_training=False (test_kitti_depth_con.py:19-65), forward only - every
+    # slim.conv2d one kernel pass (batch norm on moving statistics + ELU in the convolution's epilogue), no concat
+    pinf = A.make_decoder_params(dev, 5, moving_stats=True)
+    einf = {k: v.detach() for k, v in ends.items()}
+    for _ in range(4):
+        sfm_amd.disp_aspp_u_dense_decoder(einf, pinf, is_training=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sfm_amd.disp_aspp_u_dense_decoder(einf, pinf, is_training=False)
+    torch.cuda.synchronize()
+    ms_inf = (time.perf_counter() - t0) / reps * 1e3
     fl = 3.0 * decoder_flops(B, H // 32, W // 32)  # forward + backward-data + backward-weight
     return {"workload": f"disp_aspp_u_dense decoder (stem + 5 levels + 3 heads, random-init, synthetic ResNet end-points) -> "
                         f"normalize_disp -> multi_scale_loss (S={s3}: the decoder's three maps, N={N}, smooth_weight=0.01) -> "
                         f"backward through loss and decoder, B={B} {W}x{H} (configs[4]); host dispatch included",
             "ms_per_step": ms, "ms_decoder_fwd_bwd_alone": ms_dec, "loss": float(loss.detach()),
+            "ms_decoder_inference_fwd": ms_inf, "decoder_inference_TFLOPs": fl / 3.0 / (ms_inf * 1e-3) / 1e12,
             "decoder_conv_flops_fwd_bwd": fl, "decoder_TFLOPs_at_alone_time": fl / (ms_dec * 1e-3) / 1e12,
             "pixel_warps_per_step": B * H * W * s3 * N * 2, "Gpix_per_s": B * H * W * s3 * N * 2 / (ms * 1e-3) / 1e9}
 

@@ -299,6 +299,13 @@ int sfm_aspp_conv3x3_bwd_weight_ld(const float* in, int ld_in, const float* gout
 int sfm_aspp_conv3x3_bn_act_infer(const float* in, const float* w, const float* gamma, const float* beta,
                                   const float* moving_mean, const float* moving_var, float eps, int act, int B, int H,
                                   int W, int Cin, int Cout, int rate, float* out, float* ws, void* stream);
+/* The same one-pass convolution + batch norm (moving statistics) + ELU for the inference decoder level without a concat:
+ * ntaps = 9 (dilated 3x3) or 1 (1x1); `in` may be a channel slice of a wider NHWC buffer (ld_in floats between pixels) and
+ * `out` is written as a channel slice of the level's concat buffer (ld_out) - tf.concat of nets.py:458, 463, 467, 469 is
+ * never materialised and every slim.conv2d of the block is ONE kernel pass.  16-byte aligned, strides multiples of 4. */
+int sfm_aspp_conv_bn_act_infer_ld(const float* in, int ld_in, const float* w, int ntaps, const float* gamma, const float* beta,
+                                  const float* moving_mean, const float* moving_var, float eps, int act, int B, int H, int W,
+                                  int Cin, int Cout, int rate, float* out, int ld_out, float* ws, void* stream);
 
 /* The 1x1 convolutions of the same block (nets.py:455, 456, 461, 466, 470): slim.conv2d(x, Cout, [1, 1]) itself, w
  * [1,1,Cin,Cout], through the same implicit-GEMM kernels (centre tap only).  ws: the 3x3 workspace of the shape. */
@@ -349,6 +356,11 @@ int sfm_bn_elu_bwd(const float* x, const float* y, const float* gy, const float*
 int sfm_bn_elu_fwd_ld(const float* x, const float* gamma, const float* beta, long long M, int C, float eps, double decay,
                       int act, float* moving_mean, float* moving_var, float* y, int ld_y, float* save_mean,
                       float* save_invstd, float* ws, void* stream);
+/* slim.batch_norm(x, is_training=False) (+ tf.nn.elu if act): the moving statistics instead of the batch's - the batch
+ * norms of the inference graph (test_kitti_depth_con.py:19-65) that do not follow a convolution (nets.py:672, 460; the
+ * ones that do are the epilogue of sfm_aspp_conv_bn_act_infer_ld).  y may be a channel slice (ld_y). */
+int sfm_bn_elu_infer(const float* x, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                     long long M, int C, float eps, int act, float* y, int ld_y, void* stream);
 int sfm_bn_elu_bwd_ld(const float* x, const float* y, int ld_y, const float* const* gy, const int* ld_gy, int n_gy,
                       const float* gamma, const float* save_mean, const float* save_invstd, long long M, int C, int act,
                       float* gx, float* ggamma, float* gbeta, float* ws, void* stream);

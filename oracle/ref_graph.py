@@ -552,13 +552,20 @@ def conv1x1(x_nhwc: Tensor, w_hwio: Tensor) -> Tensor:
 
 
 def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Optional[Tensor] = None, rates=(2, 4),
-                          use_skip: bool = True, use_skip2: bool = True, skip2: Optional[Tensor] = None):
-    """nets.py:451-471 op for op; every slim.conv2d = convolution (no bias) + batch norm (training) [+ ELU unless
-    activation_fn=None] through the arg-scope of nets.py:653-656.  ``params`` as in sfm_amd.aspp."""
+                          use_skip: bool = True, use_skip2: bool = True, skip2: Optional[Tensor] = None,
+                          is_training: bool = True):
+    """nets.py:451-471 op for op; every slim.conv2d = convolution (no bias) + batch norm [+ ELU unless
+    activation_fn=None] through the arg-scope of nets.py:653-656.  ``params`` as in sfm_amd.aspp.  ``is_training=False``
+    (the inference graphs, test_kitti_depth_con.py:19-65): every batch norm on its moving statistics."""
+    def bn(y, q, activation=True):
+        if is_training:
+            return batch_norm_elu(y, q["gamma"], q["beta"], activation=activation)
+        return batch_norm_infer(y, q["gamma"], q["beta"], q["moving_mean"], q["moving_var"], activation=activation)
+
     def sc(x, name, rate=None, activation=True):
         q = params[name]
         y = conv1x1(x, q["w"]) if rate is None else dilated_conv3x3(x, q["w"], rate)
-        return batch_norm_elu(y, q["gamma"], q["beta"], activation=activation)
+        return bn(y, q, activation)
     h, w = concat.shape[1], concat.shape[2]
     upnet = sc(resize_bilinear_tf1(concat, 2 * h, 2 * w), "up", activation=False)
     supnet = sc(upnet, "sup")
@@ -566,7 +573,7 @@ def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Optional[Tens
     aspp_up2 = sc(torch.cat([supnet, aspp_up], dim=3), "aspp_up2", rate=rates[1])
     if use_skip:
         q = params["skip_bn"]
-        skip = sc(batch_norm_elu(skip_feat, q["gamma"], q["beta"]), "skip")
+        skip = sc(bn(skip_feat, q), "skip")
     else:
         skip = sc(torch.cat([aspp_up, aspp_up2], dim=3), "skip", rate=rates[1] * 2)
     parts = [supnet, aspp_up, aspp_up2, skip]
@@ -587,21 +594,25 @@ def disp_head(x_nhwc: Tensor, w_hwio: Tensor, bias: Tensor) -> Tensor:
     return DISP_SCALING * torch.sigmoid(y) + MIN_DISP
 
 
-def disp_aspp_u_dense_decoder(end_points: dict, params: dict):
+def disp_aspp_u_dense_decoder(end_points: dict, params: dict, is_training: bool = True):
     """nets.py:666-692 after the ResNet: batch norm + ELU + 1x1 (no activation) on block4 (:672-673), five
     ``disp_bottleneck_dense`` levels (:675-686), three heads (:678, 683, 689).  Returns [disp4, disp3, disp2].
     ``end_points`` / ``params`` as in sfm_amd.aspp.disp_aspp_u_dense_decoder."""
-    q = params["stem_bn"]
-    upnet = batch_norm_elu(end_points["block4"], q["gamma"], q["beta"])
+    def bn(y, q, activation=True):
+        if is_training:
+            return batch_norm_elu(y, q["gamma"], q["beta"], activation=activation)
+        return batch_norm_infer(y, q["gamma"], q["beta"], q["moving_mean"], q["moving_var"], activation=activation)
+    lvl = lambda *a, **kw: disp_bottleneck_dense(*a, is_training=is_training, **kw)  # noqa: E731
+    upnet = bn(end_points["block4"], params["stem_bn"])
     q = params["stem"]
-    upnet = batch_norm_elu(conv1x1(upnet, q["w"]), q["gamma"], q["beta"], activation=False)
-    concat, _ = disp_bottleneck_dense(params["concat"], upnet, end_points["block3"], use_skip2=False)
-    concat1, skip1 = disp_bottleneck_dense(params["concat1"], concat, end_points["block2"], use_skip2=False)
-    xconcat2, skip2 = disp_bottleneck_dense(params["concat2"], concat1, end_points["block1"], skip2=skip1)
+    upnet = bn(conv1x1(upnet, q["w"]), q, activation=False)
+    concat, _ = lvl(params["concat"], upnet, end_points["block3"], use_skip2=False)
+    concat1, skip1 = lvl(params["concat1"], concat, end_points["block2"], use_skip2=False)
+    xconcat2, skip2 = lvl(params["concat2"], concat1, end_points["block1"], skip2=skip1)
     disp2 = disp_head(xconcat2, params["disp2"]["w"], params["disp2"]["b"])
-    xconcat3, skip3 = disp_bottleneck_dense(params["concat3"], xconcat2, end_points["root_block"], rates=(3, 6), skip2=skip2)
+    xconcat3, skip3 = lvl(params["concat3"], xconcat2, end_points["root_block"], rates=(3, 6), skip2=skip2)
     disp3 = disp_head(xconcat3, params["disp3"]["w"], params["disp3"]["b"])
-    xconcat4, _ = disp_bottleneck_dense(params["concat4"], xconcat3, None, rates=(3, 6), use_skip=False, skip2=skip3)
+    xconcat4, _ = lvl(params["concat4"], xconcat3, None, rates=(3, 6), use_skip=False, skip2=skip3)
     disp4 = disp_head(xconcat4, params["disp4"]["w"], params["disp4"]["b"])
     return [disp4, disp3, disp2]
 

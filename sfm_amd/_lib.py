@@ -84,6 +84,8 @@ SIGNATURES = {
     "sfm_bn_elu_fwd": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P, _P],
     "sfm_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P],
     "sfm_bn_elu_fwd_ld": [_P, _P, _P, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _I, _P, _P, _P, _P],
+    "sfm_bn_elu_infer": [_P, _P, _P, _P, _P, _LL, _I, _F, _I, _P, _I, _P],
+    "sfm_aspp_conv_bn_act_infer_ld": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "sfm_bn_elu_bwd_ld": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P],
     "sfm_bn_local_stats": [_P, _LL, _I, _P, _P, _P],
     "sfm_bn_elu_apply_stats": [_P, _P, _P, _P, _I, _LL, _I, _F, ctypes.c_double, _I, _P, _P, _P, _P, _P, _P],

@@ -518,7 +518,9 @@ class _DenseLevel(torch.autograd.Function):
         return (None, g_concat, g_skip_feat, g_skip2, *flat)
 
 
-def _dense_level(params, concat, skip_feat, rates, use_skip, use_skip2, skip2):
+def _check_level(params, concat, skip_feat, use_skip, use_skip2, skip2, need_moving=False):
+    """argument checks of the concat-free level (the kernels index with these sizes and check nothing themselves) ->
+    (names, flat parameter list, moving statistics per name, concat, skip_feat, skip2)"""
     names = [n for n in _LEVEL_CONVS if n != "skip2" or use_skip2] + (["skip_bn"] if use_skip else [])
     concat = _check(concat, "concat", 4)
     B, h, w_ = concat.shape[:3]
@@ -558,18 +560,82 @@ def _dense_level(params, concat, skip_feat, rates, use_skip, use_skip2, skip2):
         _same_device(concat, *([q["w"]] if nm != "skip_bn" else []), *tensors.values())
         flat += vecs if nm == "skip_bn" else [q["w"], *vecs]
         extras[nm] = {k: q[k] for k in ("moving_mean", "moving_var") if q.get(k) is not None}
+        if need_moving and len(extras[nm]) != 2:
+            raise ValueError(f"is_training=False needs {nm}.moving_mean and {nm}.moving_var")
+    return names, flat, extras, concat, skip_feat, skip2
+
+
+def _dense_level(params, concat, skip_feat, rates, use_skip, use_skip2, skip2):
+    names, flat, extras, concat, skip_feat, skip2 = _check_level(params, concat, skip_feat, use_skip, use_skip2, skip2)
     cfg = (tuple(names), tuple(int(r) for r in rates), bool(use_skip), bool(use_skip2), extras)
     return _DenseLevel.apply(cfg, concat, skip_feat if use_skip else None, skip2 if use_skip2 else None, *flat)
 
 
+def _infer_conv(x, ld, q, dims, rate, act, y, ld_y):
+    """one slim.conv2d of the inference graph in ONE kernel pass: convolution, batch norm on the moving statistics, ELU if
+    act, written to y (a tensor of its own or a channel slice of the level's concat buffer, row stride ld_y)"""
+    B, H, W = dims
+    w = q["w"]
+    taps, Cin, Cout = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+    ws = _workspace(B, H, W, Cin, Cout, x.device)
+    call("sfm_aspp_conv_bn_act_infer_ld", ptr(x), ld, ptr(w), taps, ptr(q["gamma"]), ptr(q["beta"]), ptr(q["moving_mean"]),
+         ptr(q["moving_var"]), float(BN_EPSILON), int(act), B, H, W, Cin, Cout, int(rate) if taps == 9 else 1, ptr(y), ld_y,
+         ptr(ws), stream_of(x))
+
+
+def _infer_bn(x, q, act, y, ld_y):
+    C = x.shape[-1]
+    call("sfm_bn_elu_infer", ptr(x), ptr(q["gamma"]), ptr(q["beta"]), ptr(q["moving_mean"]), ptr(q["moving_var"]),
+         x.numel() // C, C, float(BN_EPSILON), int(act), ptr(y), ld_y, stream_of(x))
+
+
+def _dense_level_infer(params, concat, skip_feat, rates, use_skip, use_skip2, skip2):
+    """the level under is_training=False (test_kitti_depth_con.py:19-65): forward only, every slim.conv2d one kernel pass
+    (batch norm on the moving statistics + ELU as the convolution's epilogue), outputs written as channel slices of the
+    level's one concat buffer - nine launches + two resizes for the whole of nets.py:451-471"""
+    names, _, _, concat, skip_feat, skip2 = _check_level(params, concat, skip_feat, use_skip, use_skip2, skip2, need_moving=True)
+    P = params
+    B, h, w_, _ = concat.shape
+    H, W = 2 * h, 2 * w_
+    dims = (B, H, W)
+    C, Cin = P["sup"]["w"].shape[3], P["up"]["w"].shape[3]
+    nC = (5 if use_skip2 else 4) * C
+    dev = concat.device
+    with torch.no_grad(), torch.cuda.device(dev):
+        u0 = _raw_resize(concat, H, W)                                                          # :454
+        upnet = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dev)
+        _infer_conv(u0, u0.shape[3], P["up"], dims, 0, 0, upnet, Cin)                           # :455
+        X = torch.empty(B, H, W, nC, dtype=torch.float32, device=dev)
+        sl = lambda a, b: X[..., a * C:b * C]                                                   # noqa: E731
+        _infer_conv(upnet, Cin, P["sup"], dims, 0, 1, sl(0, 1), nC)                             # :456
+        _infer_conv(upnet, Cin, P["aspp_up"], dims, rates[0], 1, sl(1, 2), nC)                  # :457
+        _infer_conv(sl(0, 2), nC, P["aspp_up2"], dims, rates[1], 1, sl(2, 3), nC)               # :458
+        if use_skip:
+            sk = torch.empty_like(skip_feat)
+            _infer_bn(skip_feat, P["skip_bn"], 1, sk, sk.shape[3])                              # :460
+            _infer_conv(sk, sk.shape[3], P["skip"], dims, 0, 1, sl(3, 4), nC)                   # :461
+        else:
+            _infer_conv(sl(1, 3), nC, P["skip"], dims, rates[1] * 2, 1, sl(3, 4), nC)           # :463
+        if use_skip2:
+            s2 = _raw_resize(skip2, H, W)                                                       # :465
+            _infer_conv(s2, s2.shape[3], P["skip2"], dims, 0, 1, sl(4, 5), nC)                  # :466
+        xconcat = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+        _infer_conv(X, nC, P["out"], dims, 0, 0, xconcat, C)                                    # :470
+    return xconcat, upnet
+
+
 def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None, rates=(2, 4), use_skip: bool = True,
-                          use_skip2: bool = True, skip2: Tensor = None, process_group=None, fused_level: bool = True):
+                          use_skip2: bool = True, skip2: Tensor = None, process_group=None, fused_level: bool = True,
+                          is_training: bool = True):
     """``nets.disp_bottleneck_dense`` (nets.py:451-471), one decoder level of ``disp_aspp_u_dense``, every op a
     hand-written kernel: x2 bilinear upsample, 1x1 and dilated 3x3 convolutions on fp32 MFMA, batch norm (training) +
     ELU.  ``fused_level`` (default; single-rank statistics only): the level is ONE autograd node that never materialises
     a concat - the batch norms write channel slices of one buffer, the convolutions read slices of it, the backward sums
     the gradients of an activation's several readers while loading them (``_DenseLevel``); False, or a ``process_group``:
-    the operators composed through autograd with ``torch.cat``.  ``params``: name -> dict(w, gamma, beta[, moving_mean, moving_var]) for
+    the operators composed through autograd with ``torch.cat``.  ``is_training=False`` (the inference graphs,
+    test_kitti_depth_con.py:19-65; every parameter dict then needs ``moving_mean`` / ``moving_var``): forward only, every
+    ``slim.conv2d`` ONE kernel pass with the batch norm on the moving statistics and the ELU as the convolution's epilogue,
+    written as channel slices of the level's concat buffer.  ``params``: name -> dict(w, gamma, beta[, moving_mean, moving_var]) for
     'up' (:455), 'sup' (:456), 'aspp_up' (:457), 'aspp_up2' (:458), 'skip' (:461 or :463), ['skip2' (:466)], 'out'
     (:470) and, with use_skip, 'skip_bn' = dict(gamma, beta, ...) for the batch norm of the skip feature (:460).
     ``skip_feat`` = end_points[skip_block].  Returns (xconcat, upnet) like the reference.  ``process_group``: every
@@ -577,6 +643,8 @@ def disp_bottleneck_dense(params: dict, concat: Tensor, skip_feat: Tensor = None
     from .pyramid import resize_bilinear
     import functools
     import os
+    if not is_training:
+        return _dense_level_infer(params, concat, skip_feat, rates, use_skip, use_skip2, skip2)
     if process_group is None and fused_level and os.environ.get("SFM_LEVEL_FUSED", "1") != "0":
         return _dense_level(params, concat, skip_feat, rates, use_skip, use_skip2, skip2)
     conv = functools.partial(_slim_conv, process_group=process_group)
@@ -652,7 +720,7 @@ def disp_head(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
     return _DispHead.apply(x, w, b)
 
 
-def disp_aspp_u_dense_decoder(end_points: dict, params: dict, process_group=None):
+def disp_aspp_u_dense_decoder(end_points: dict, params: dict, process_group=None, is_training: bool = True):
     """The decoder of ``nets.disp_aspp_u_dense`` (nets.py:666-692) from the ResNet end-points to the three disparity
     maps - everything of the network that is not the stock ResNet-v2-50 encoder: batch norm + ELU + 1x1 on block4
     (:672-673), the five ``disp_bottleneck_dense`` levels (:675-686) and the three heads (:678, 683, 689).
@@ -662,20 +730,38 @@ def disp_aspp_u_dense_decoder(end_points: dict, params: dict, process_group=None
     for a 128 x 416 image).  ``params``: 'stem_bn' = dict(gamma, beta[, moving_mean, moving_var]) (:672), 'stem' =
     dict(w [1,1,2048,1024], gamma, beta, ...) (:673), 'concat', 'concat1', 'concat2', 'concat3', 'concat4' = the
     parameter dicts of ``disp_bottleneck_dense``, 'disp2', 'disp3', 'disp4' = dict(w [3,3,C,1], b [1]).
-    Returns ``[disp4, disp3, disp2]`` like the reference ([B,32h,32w,1], [B,16h,16w,1], [B,8h,8w,1])."""
+    Returns ``[disp4, disp3, disp2]`` like the reference ([B,32h,32w,1], [B,16h,16w,1], [B,8h,8w,1]).
+    ``is_training=False`` (test_kitti_depth_con.py:19-65; ``moving_mean`` / ``moving_var`` in every batch-norm dict): the
+    serving path - forward only, no autograd graph, one kernel pass per ``slim.conv2d``, no concat."""
     q = params["stem_bn"]
-    upnet = batch_norm_elu(end_points["block4"], q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"),
-                           process_group=process_group)                                                      # :672
-    upnet = _slim_conv(upnet, params, "stem", activation=False, process_group=process_group)                 # :673
-    lvl = lambda name, x, skip, **kw: disp_bottleneck_dense(params[name], x, skip, process_group=process_group, **kw)  # noqa: E731
-    concat, _ = lvl("concat", upnet, end_points["block3"], use_skip2=False)                                  # :675
-    concat1, skip1 = lvl("concat1", concat, end_points["block2"], use_skip2=False)                           # :676
-    xconcat2, skip2 = lvl("concat2", concat1, end_points["block1"], skip2=skip1)                             # :677
-    disp2 = disp_head(xconcat2, params["disp2"]["w"], params["disp2"]["b"])                                  # :678
-    xconcat3, skip3 = lvl("concat3", xconcat2, end_points["root_block"], rates=(3, 6), skip2=skip2)          # :681
-    disp3 = disp_head(xconcat3, params["disp3"]["w"], params["disp3"]["b"])                                  # :683
-    xconcat4, _ = lvl("concat4", xconcat3, None, rates=(3, 6), use_skip=False, skip2=skip3)                  # :686
-    disp4 = disp_head(xconcat4, params["disp4"]["w"], params["disp4"]["b"])                                  # :689
+    if not is_training:
+        x4 = _check(end_points["block4"], "block4", 4)
+        for nm in ("stem_bn", "stem"):
+            if params[nm].get("moving_mean") is None or params[nm].get("moving_var") is None:
+                raise ValueError(f"is_training=False needs {nm}.moving_mean and {nm}.moving_var")
+        with torch.no_grad(), torch.cuda.device(x4.device):
+            B, h, w_, c4 = x4.shape
+            t = torch.empty_like(x4)
+            _infer_bn(x4, q, 1, t, c4)                                                                       # :672
+            co = params["stem"]["w"].shape[3]
+            upnet = torch.empty(B, h, w_, co, dtype=torch.float32, device=x4.device)
+            _infer_conv(t, c4, params["stem"], (B, h, w_), 0, 0, upnet, co)                                  # :673
+    else:
+        upnet = batch_norm_elu(end_points["block4"], q["gamma"], q["beta"], q.get("moving_mean"), q.get("moving_var"),
+                               process_group=process_group)                                                  # :672
+        upnet = _slim_conv(upnet, params, "stem", activation=False, process_group=process_group)             # :673
+    lvl = lambda name, x, skip, **kw: disp_bottleneck_dense(params[name], x, skip, process_group=process_group,  # noqa: E731
+                                                            is_training=is_training, **kw)
+    import contextlib
+    with (contextlib.nullcontext() if is_training else torch.no_grad()):
+        concat, _ = lvl("concat", upnet, end_points["block3"], use_skip2=False)                                  # :675
+        concat1, skip1 = lvl("concat1", concat, end_points["block2"], use_skip2=False)                           # :676
+        xconcat2, skip2 = lvl("concat2", concat1, end_points["block1"], skip2=skip1)                             # :677
+        disp2 = disp_head(xconcat2, params["disp2"]["w"], params["disp2"]["b"])                                  # :678
+        xconcat3, skip3 = lvl("concat3", xconcat2, end_points["root_block"], rates=(3, 6), skip2=skip2)          # :681
+        disp3 = disp_head(xconcat3, params["disp3"]["w"], params["disp3"]["b"])                                  # :683
+        xconcat4, _ = lvl("concat4", xconcat3, None, rates=(3, 6), use_skip=False, skip2=skip3)                  # :686
+        disp4 = disp_head(xconcat4, params["disp4"]["w"], params["disp4"]["b"])                                  # :689
     return [disp4, disp3, disp2]
 
 
@@ -685,9 +771,11 @@ DECODER_LEVELS = (  # name, Cin, Cout, skip end-point (channels) or None, channe
     ("concat4", 64, 32, None, 128))
 
 
-def make_decoder_params(device, seed: int = 0, width_div: int = 1) -> dict:
+def make_decoder_params(device, seed: int = 0, width_div: int = 1, moving_stats: bool = False) -> dict:
     """Random-init parameters of ``disp_aspp_u_dense_decoder`` in the layout it reads (He-style weights, gamma ~ 1,
-    beta ~ 0; moving statistics omitted).  ``width_div``: every channel count divided by it (small test decoders)."""
+    beta ~ 0).  ``width_div``: every channel count divided by it (small test decoders).  ``moving_stats``: every batch norm
+    also gets ``moving_mean`` ~ 0.1 N(0,1) and ``moving_var`` ~ U(0.5, 1.5) (drawn from a generator of their own: the other
+    parameters of a seed do not change) - what ``is_training=False`` reads."""
     g = torch.Generator().manual_seed(seed)
     dv = lambda c: max(32, c // width_div)  # noqa: E731
 
@@ -716,6 +804,20 @@ def make_decoder_params(device, seed: int = 0, width_div: int = 1) -> dict:
     for name, c in (("disp2", 128), ("disp3", 64), ("disp4", 32)):
         c = dv(c)
         p[name] = dict(w=(torch.randn(3, 3, c, 1, generator=g) / (3 * c ** 0.5)).to(device), b=vec(1, 0.1, 0.0))
+    if moving_stats:
+        g2 = torch.Generator().manual_seed(seed + 7919)
+
+        def add(q):
+            c = q["gamma"].shape[0]
+            q["moving_mean"] = (torch.randn(c, generator=g2) * 0.1).to(device)
+            q["moving_var"] = (torch.rand(c, generator=g2) + 0.5).to(device)
+        for q in p.values():
+            if "gamma" in q:
+                add(q)
+            else:
+                for qq in q.values():
+                    if isinstance(qq, dict) and "gamma" in qq:
+                        add(qq)
     return p
 
 

@@ -142,7 +142,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 + (STAGES == 3 ? 256 : (
 __attribute__((amdgpu_waves_per_eu(STAGES == 3 ? 3 : 4, STAGES == 3 ? 3 : 4)))
 void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ out,
                          float* __restrict__ partial, int B, int H, int W, int Cin, int Cout, int rate, int ntaps, Epilogue ep,
-                         int lda) {  // lda: floats between the rows of `in` (Cin, or more when `in` is a channel slice)
+                         int lda,    // floats between the rows of `in` (Cin, or more when `in` is a channel slice)
+                         int ldc) {  // ... and of `out` (Cout, or more when the outputs are a channel slice of a wider buffer)
   constexpr int NW = (BM / WM) * (BN / WN), NL = STAGES == 3 ? 4 : NW;  // multiplier waves, loader waves
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN;
@@ -400,8 +401,8 @@ void aspp_conv_sk_kernel(const float* __restrict__ in, const float* __restrict__
     int lane_o = lane, wm0_o = wm0;
     asm volatile("" : "+v"(lane_o), "+s"(wm0_o));
     if (kb == 0 && ke == K) {  // the whole tile: straight to the output
-      if constexpr (EP) store_acc<TM, TN>(acc, out, Cout, m0 + wm0_o, M, n0 + wn0, ep, lane_o);
-      else store_acc<TM, TN>(acc, out, Cout, m0 + wm0_o, M, n0 + wn0, Epilogue{nullptr, nullptr, 0}, lane_o);
+      if constexpr (EP) store_acc<TM, TN>(acc, out, ldc, m0 + wm0_o, M, n0 + wn0, ep, lane_o);
+      else store_acc<TM, TN>(acc, out, ldc, m0 + wm0_o, M, n0 + wn0, Epilogue{nullptr, nullptr, 0}, lane_o);
     } else {  // part of a tile: this workgroup's head (slab 0: the range starts inside the tile) or tail (slab 1)
       float* slab = partial + (wg * 2 + (u == u0 ? 0 : 1)) * (BM * BN);
       store_acc<TM, TN>(acc, slab, BN, wm0_o, BM, wn0, Epilogue{nullptr, nullptr, 0}, lane_o);
@@ -482,7 +483,8 @@ __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_kernel(const float* __re
 // convolution mostly on workgroups that found their tile uncut after a round of 64-bit divisions.)
 template <int BM, int BN>
 __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_cut_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                   long M, int Cout, int K, long nwg, long total, Epilogue ep) {
+                                                                   long M, int Cout, int K, long nwg, long total, Epilogue ep,
+                                                                   int ldc) {
   const long b = blockIdx.x;  // the boundary between workgroups b and b + 1
   const long u = sk_first_unit(b + 1, total, nwg);
   const long t = u / K, ta = t * K, tb = ta + K;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void aspp_sk_fixup_cut_kernel(const float* 
     s = make_float4(ep_apply(s.x, sc.x, sh.x, ep.act), ep_apply(s.y, sc.y, sh.y, ep.act), ep_apply(s.z, sc.z, sh.z, ep.act),
                     ep_apply(s.w, sc.w, sh.w, ep.act));
   }
-  *reinterpret_cast<float4*>(out + orow * Cout + n0 + c4) = s;
+  *reinterpret_cast<float4*>(out + orow * ldc + n0 + c4) = s;
 }
 
 // ------------------------------------------------------------------ backward weight, stream-K + LDS-DMA + loader waves
@@ -983,9 +985,11 @@ static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int rate) {
 // ntaps = 9: the dilated 3x3; ntaps = 1: a 1x1 convolution = the same kernels on the centre tap alone (rate 0 makes every
 // tap offset zero, the weights are [1][Cin][Cout]).
 static int launch_conv(const float* in, const float* wt, float* out, float* slabs, int B, int H, int W, int Cin, int Cout,
-                       int rate, hipStream_t stream, int ntaps = 9, Epilogue ep = Epilogue{nullptr, nullptr, 0}, int lda = 0) {
+                       int rate, hipStream_t stream, int ntaps = 9, Epilogue ep = Epilogue{nullptr, nullptr, 0}, int lda = 0,
+                       int ldc = 0) {
   const long M = (long)B * H * W;
   if (lda == 0) lda = Cin;
+  if (ldc == 0) ldc = Cout;
   const ConvPlan p = conv_plan(M, Cin, Cout, ntaps);
   if (ntaps == 1) rate = 0;
   const int K = ntaps * (Cin / BK);
@@ -994,13 +998,13 @@ static int launch_conv(const float* in, const float* wt, float* out, float* slab
   do {                                                                                                                  \
     if (ep.scale)                                                                                                       \
       hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, true, ST_>), dim3((unsigned)p.nwg), dim3(NT_), 0, stream, in, wt, \
-                         out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep, lda);                                         \
+                         out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep, lda, ldc);                                    \
     else                                                                                                                \
       hipLaunchKernelGGL((aspp_conv_sk_kernel<BM_, BN_, WM_, WN_, false, ST_>), dim3((unsigned)p.nwg), dim3(NT_), 0, stream, in,    \
-                         wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep, lda);                                     \
+                         wt, out, slabs, B, H, W, Cin, Cout, rate, ntaps, ep, lda, ldc);                                \
     if (p.nwg > 1)                                                                                                      \
       hipLaunchKernelGGL((aspp_sk_fixup_cut_kernel<BM_, BN_>), dim3((unsigned)(p.nwg - 1), BM_ * BN_ / 4 / kBlock), dim3(kBlock), \
-                         0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, ep);                                      \
+                         0, stream, slabs, out, M, Cout, K, p.nwg, tiles * K, ep, ldc);                                 \
   } while (0)
   if (p.cfg == 3)
     SFM_CONV_LAUNCH(256, 128, 64, 64, 3, 768);
@@ -1086,6 +1090,27 @@ extern "C" int sfm_aspp_conv3x3_bn_act_infer(const float* in, const float* w, co
   hipLaunchKernelGGL(aspp_bn_fold_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, gamma, beta, moving_mean, moving_var,
                      eps, Cout, scale, shift);
   return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, rate, stream, 9, Epilogue{scale, shift, act});
+}
+
+// The inference decoder level without a concat (the serving path: test_kitti_depth_con.py:19-65 builds the net with
+// is_training=False): the same one-pass convolution + batch norm (moving statistics) + ELU with `in` a channel slice of a
+// wider buffer (ld_in) and `out` written as a channel slice of the level's concat buffer (ld_out) - one slim.conv2d = one
+// kernel pass, the concat of nets.py:458, 463, 467, 469 never materialised.  ntaps = 9 (3x3, `rate`) or 1 (1x1).
+extern "C" int sfm_aspp_conv_bn_act_infer_ld(const float* in, int ld_in, const float* w, int ntaps, const float* gamma,
+                                             const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                                             int act, int B, int H, int W, int Cin, int Cout, int rate, float* out, int ld_out,
+                                             float* ws, void* stream_) {
+  if ((ntaps != 1 && ntaps != 9) || !in || !w || !moving_mean || !moving_var || !out || !ws ||
+      !conv_dims_ok(B, H, W, Cin, Cout, ntaps == 9 ? rate : 1) || !slice_ok(in, ld_in, Cin, (long)B * H * W) ||
+      !slice_ok(out, ld_out, Cout, (long)B * H * W))
+    return SFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long total = sfm_aspp_conv3x3_workspace_floats(B, H, W, Cin, Cout);
+  float* scale = ws + (total - 4 - 2L * Cout);
+  float* shift = scale + Cout;
+  hipLaunchKernelGGL(aspp_bn_fold_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, gamma, beta, moving_mean, moving_var,
+                     eps, Cout, scale, shift);
+  return launch_conv(in, w, out, ws, B, H, W, Cin, Cout, rate, stream, ntaps, Epilogue{scale, shift, act}, ld_in, ld_out);
 }
 
 // dL/d in [B,H,W,Cin] from gout = dL/d out [B,H,W,Cout] (TF autodiff of the same call).

@@ -224,6 +224,27 @@ __global__ __launch_bounds__(kBlock) void bn_elu_apply_kernel(const float* __res
   *reinterpret_cast<float4*>(y + row * ldy + 4 * g) = o;  // ldy = C: y is a tensor of its own; more: a slice of the concat buffer
 }
 
+// inference (is_training=False): the moving statistics instead of the batch's, y = gamma (x - mm) rsqrt(mv + eps) + beta
+__global__ __launch_bounds__(kBlock) void bn_elu_infer_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ mm,
+                                                              const float* __restrict__ mv, float eps, long n4, int groups,
+                                                              int act, float* __restrict__ y, int ldy) {
+  const long e = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n4) return;
+  const long row = e / groups;
+  const int g = (int)(e - row * groups);
+  const float4 xv = reinterpret_cast<const float4*>(x)[e];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[g], be = reinterpret_cast<const float4*>(beta)[g];
+  const float4 m = reinterpret_cast<const float4*>(mm)[g], v = reinterpret_cast<const float4*>(mv)[g];
+  float4 o;
+  o.x = ga.x * ((xv.x - m.x) * (1.0f / sqrtf(v.x + eps))) + be.x;
+  o.y = ga.y * ((xv.y - m.y) * (1.0f / sqrtf(v.y + eps))) + be.y;
+  o.z = ga.z * ((xv.z - m.z) * (1.0f / sqrtf(v.z + eps))) + be.z;
+  o.w = ga.w * ((xv.w - m.w) * (1.0f / sqrtf(v.w + eps))) + be.w;
+  if (act) { o.x = elu(o.x); o.y = elu(o.y); o.z = elu(o.z); o.w = elu(o.w); }
+  *reinterpret_cast<float4*>(y + row * ldy + 4 * g) = o;
+}
+
 __global__ __launch_bounds__(kBlock) void bn_elu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                   int ldy, GySrc gy, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean,
@@ -285,6 +306,20 @@ extern "C" int sfm_bn_elu_fwd_ld(const float* x, const float* gamma, const float
   const long n4 = (long)M * p.groups;
   hipLaunchKernelGGL(bn_elu_apply_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, x, gamma, beta,
                      save_mean, save_invstd, n4, p.groups, act, y, ld_y);
+  return sfm_last_error();
+}
+
+// slim.batch_norm(x, is_training=False) (+ tf.nn.elu): the batch norms of the inference graph that do not follow a
+// convolution (nets.py:672, 460 under test_kitti_depth_con.py's is_training=False); y may be a channel slice (ld_y)
+extern "C" int sfm_bn_elu_infer(const float* x, const float* gamma, const float* beta, const float* moving_mean,
+                                const float* moving_var, long long M, int C, float eps, int act, float* y, int ld_y,
+                                void* stream_) {
+  BnPlan p;
+  if (!x || !gamma || !beta || !moving_mean || !moving_var || !slice_ok(y, ld_y, C) || !bn_plan((long)M, C, p) || !(eps > 0.0f))
+    return SFM_ERR_ARG;
+  const long n4 = (long)M * p.groups;
+  hipLaunchKernelGGL(bn_elu_infer_kernel, dim3((unsigned)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream_, x,
+                     gamma, beta, moving_mean, moving_var, eps, n4, p.groups, act, y, ld_y);
   return sfm_last_error();
 }
 

@@ -148,3 +148,37 @@ def test_decoder_chained_into_the_loss(dev):
         if e > 2e-3:
             bad[name] = e
     assert not bad, bad
+
+
+def _to(params, device):
+    return {k: ({kk: (({k3: v3.to(device) for k3, v3 in vv.items()}) if isinstance(vv, dict) else vv.to(device))
+                 for kk, vv in v.items()}) for k, v in params.items()}
+
+
+@pytest.mark.parametrize("B,h,w,width_div,tol", [(2, 2, 3, 8, 1e-4), (8, 4, 13, 1, 3e-4)], ids=["small", "configs[4] size"])
+def test_decoder_inference_mode(dev, B, h, w, width_div, tol):
+    """is_training=False (test_kitti_depth_con.py:19-65): every batch norm on its moving statistics, folded with the ELU
+    into the convolution that precedes it and written as a channel slice of the level's concat buffer - against the
+    oracle's op-for-op inference graph; no autograd graph is built; the moving statistics stay untouched"""
+    params = A.make_decoder_params("cpu", 21, width_div, moving_stats=True)
+    ends = A.make_end_points(B, h, w, "cpu", 21, width_div)
+    with torch.no_grad():
+        do = R.disp_aspp_u_dense_decoder(ends, params, is_training=False)
+    pg = _to(params, dev)
+    before = pg["concat"]["up"]["moving_mean"].clone()
+    dg = sfm_amd.disp_aspp_u_dense_decoder({k: v.to(dev) for k, v in ends.items()}, pg, is_training=False)
+    assert all(not t.requires_grad and t.grad_fn is None for t in dg)
+    assert torch.equal(pg["concat"]["up"]["moving_mean"], before)
+    worst = max(rel_err(a, b) for a, b in zip(dg, do))
+    print(f"decoder inference {B}x{32 * h}x{32 * w}: worst output rel err {worst:.2e}")
+    assert worst <= tol
+    # and it differs from the training-mode graph on the same inputs (the statistics really are the moving ones)
+    dt = sfm_amd.disp_aspp_u_dense_decoder({k: v.to(dev) for k, v in ends.items()}, pg)
+    assert max(rel_err(a, b) for a, b in zip(dt, dg)) > 1e-3
+
+
+def test_inference_mode_needs_moving_statistics(dev):
+    params = _to(A.make_decoder_params("cpu", 22, 8), dev)
+    ends = {k: v.to(dev) for k, v in A.make_end_points(1, 2, 3, "cpu", 22, 8).items()}
+    with pytest.raises(ValueError, match="moving_mean"):
+        sfm_amd.disp_aspp_u_dense_decoder(ends, params, is_training=False)
