@@ -227,11 +227,21 @@ struct SplatWave {
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
+#ifdef SFM_ABL_SHARED_MOMENTS  // timing ablation only (wrong numbers): the window moments of src as if precomputed once per step
+      const float in3[3] = {xv[ch], xv[ch] * xv[ch] + yv[ch] * yv[ch], xv[ch] * yv[ch]};
+      float h3[3];
+      hsum3(in3, h3, taps);
+      mom[ch][0] = vpush(P1[ch][0], P0[ch][0], h3[0]);
+      mom[ch][1] = Y[S1][ch];
+      mom[ch][2] = vpush(P1[ch][2], P0[ch][2], h3[1]);
+      mom[ch][3] = vpush(P1[ch][3], P0[ch][3], h3[2]);
+#else
       const float in4[4] = {xv[ch], yv[ch], xv[ch] * xv[ch] + yv[ch] * yv[ch], xv[ch] * yv[ch]};
       float h4[4];
       hsum3(in4, h4, taps);
 #pragma unroll
       for (int m = 0; m < 4; ++m) mom[ch][m] = vpush(P1[ch][m], P0[ch][m], h4[m]);
+#endif
     }
     nsum3(nz, nzh);
     // ---- row q = r - 1: windowed moments -> SSIM value, derivative coefficients, mask, sums
@@ -445,11 +455,20 @@ __device__ __forceinline__ void gather_item(const StencilArgs& a, long item, flo
     for (int ch = 0; ch < 3; ++ch) {
       X0[S0][ch] = x0[ch]; X1[S0][ch] = x1[ch]; T[S0][ch] = t[ch];
       const float tt = t[ch] * t[ch];
+#ifdef SFM_ABL_SHARED_MOMENTS  // timing ablation only (wrong numbers): the window moments of tgt as if precomputed once per step
+      const float in6[6] = {x0[ch], x1[ch], x0[ch] * x0[ch] + tt, x1[ch] * x1[ch] + tt, x0[ch] * t[ch], x1[ch] * t[ch]};
+      float h6[6];
+      hsum3(in6, h6, taps);
+      mm[ch][0] = T[S1][ch];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) mm[ch][m + 1] = vpush(P1[ch][m + 1], P0[ch][m + 1], h6[m]);
+#else
       const float in7[7] = {t[ch], x0[ch], x1[ch], x0[ch] * x0[ch] + tt, x1[ch] * x1[ch] + tt, x0[ch] * t[ch], x1[ch] * t[ch]};
       float h7[7];
       hsum3(in7, h7, taps);
 #pragma unroll
       for (int m = 0; m < 7; ++m) mm[ch][m] = vpush(P1[ch][m], P0[ch][m], h7[m]);
+#endif
     }
     const int q = r - 1;
     if (r - r_first >= 2) {
