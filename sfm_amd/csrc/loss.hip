@@ -346,6 +346,9 @@ __global__ __launch_bounds__(kSplatThreads) SFM_SPLAT_WPE_ATTR void loss_splat_t
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float w = sw.g[q];
+#ifdef SFM_ABL_HALF_ATOMICS  // timing ablation only (wrong numbers): the LDS atomics of the x1 corners as if a neighbouring lane had taken them
+      if (q >= 2) continue;
+#endif
       if (scan) {
         const int lx = cx[q] - x0, ly = cy[q] - y0;
         if ((unsigned)lx < (unsigned)STW && (unsigned)ly < (unsigned)STH) {
