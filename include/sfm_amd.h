@@ -55,7 +55,7 @@ int sfm_project_coords(const float* depth, const float* trans, const float* para
                        float* coords, float* z, void* stream);
 
 /* ---- the geometry helpers as stand-alone operators (utils.py exports them; the fused kernels keep the same
- * arithmetic in registers and never call these).  Forward only, canonical fp32 op order (k-ordered dot products, no
+ * arithmetic in registers and never call these).  Forward: canonical fp32 op order (k-ordered dot products, no
  * FMA, sin / cos rounded once from fp64, partial-pivot LU inverse).
  * euler2mat utils.py:27-75: z, y, x [B] (the reference's [B,1]) -> out [B,1,3,3], R = X.Y.Z, angles clipped to +-pi.
  * pose_vec2mat utils.py:77-96: vec [B,6] = (tx,ty,tz,rx,ry,rz) -> out [B,4,4].
@@ -69,6 +69,21 @@ int sfm_meshgrid(int B, int H, int W, int is_homogeneous, float* out, void* stre
 int sfm_pixel2cam(const float* depth, const float* pixel_coords, const float* K, const float* trans, int B, int H, int W,
                   int is_homogeneous, float* kinv_ws, float* out, void* stream);
 int sfm_cam2pixel(const float* cam_coords, const float* proj, int B, int H, int W, float* coords, float* z, void* stream);
+/* Their adjoints (what tf.gradients, SfMLearner_uni.py:306, derives when the caller composes utils.py:185-202 itself).
+ * g_out: gradient of the forward's output, same layout.  euler2mat: clip_by_value passes the gradient inside [-pi, pi].
+ * pixel2cam: any of g_depth [B,H,W], g_pix [B,3,H,W], g_K [B,3,3] (through the matrix inverse), g_trans [B,H,W,3] may be
+ * NULL (not wanted).  cam2pixel: g_coords / g_z may be NULL (that output was unused; not both), g_cam [B,4,H,W] / g_proj
+ * [B,4,4] may be NULL (not both).  The sums over the pixels (g_K, g_proj) go through per-workgroup partials added in a
+ * fixed order.  ws: sfm_geom_bwd_workspace_floats(B, H, W) floats. */
+int sfm_euler2mat_bwd(const float* z, const float* y, const float* x, const float* g_out, int B, float* gz, float* gy, float* gx,
+                      void* stream);
+int sfm_pose_vec2mat_bwd(const float* vec, const float* g_out, int B, float* g_vec, void* stream);
+long long sfm_geom_bwd_workspace_floats(int B, int H, int W);
+int sfm_pixel2cam_bwd(const float* depth, const float* pixel_coords, const float* K, const float* trans, const float* g_cam, int B,
+                      int H, int W, int is_homogeneous, float* g_depth, float* g_pix, float* g_K, float* g_trans, float* ws,
+                      void* stream);
+int sfm_cam2pixel_bwd(const float* cam_coords, const float* proj, const float* g_coords, const float* g_z, int B, int H, int W,
+                      float* g_cam, float* g_proj, float* ws, void* stream);
 
 /* ---- gather direction --------------------------------------------------------------
  * bilinear_sampler utils.py:241-340.  out [B,Ht,Wt,C], mask [B,Ht,Wt,1].

@@ -31,6 +31,11 @@ SIGNATURES = {
     "sfm_meshgrid": [_I, _I, _I, _I, _P, _P],
     "sfm_pixel2cam": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "sfm_cam2pixel": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "sfm_euler2mat_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
+    "sfm_pose_vec2mat_bwd": [_P, _P, _I, _P, _P],
+    "sfm_geom_bwd_workspace_floats": [_I, _I, _I],
+    "sfm_pixel2cam_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "sfm_cam2pixel_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "sfm_project_coords": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "sfm_bilinear_sampler_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sfm_bilinear_sampler_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],

@@ -340,47 +340,91 @@ def corner_indices(imgs_shape, coords):
     return idx
 
 
-class _HipForward(torch.autograd.Function):
-    """Forward = the hand-written kernel (canonical fp32 op order, bit-exact against the oracle); backward = torch
-    autograd of the same formula in torch device ops (``torch_fn``), re-evaluated on the saved inputs.  The fused
-    operators above have hand-written adjoints; these helpers are only per-batch glue for callers that compose the
-    reference's pieces themselves."""
+# ---- the geometry helpers: hand-written kernels in both directions (csrc/geom.hip).  Forward in the oracle's canonical
+# fp32 op order (bit-exact); the adjoints are what tf.gradients derives for a caller that composes utils.py:185-202 from
+# the pieces (the fused operators above never call them).
+
+def _geom_ws(B, H, W, device):
+    return torch.empty(_lib.load().sfm_geom_bwd_workspace_floats(B, H, W), dtype=torch.float32, device=device)
+
+
+class _Euler2Mat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, y, x):
+        ctx.save_for_backward(z, y, x)
+        return _euler2mat_hip(z, y, x)
 
     @staticmethod
-    def forward(ctx, hip_fn, torch_fn, *tensors):
-        ctx.torch_fn = torch_fn
-        ctx.save_for_backward(*tensors)
-        with torch.no_grad():
-            out = hip_fn(*tensors)
-        return out
+    def backward(ctx, g):
+        z, y, x = ctx.saved_tensors
+        gz, gy, gx = torch.empty_like(z), torch.empty_like(y), torch.empty_like(x)
+        with torch.cuda.device(z.device):
+            call("sfm_euler2mat_bwd", ptr(z), ptr(y), ptr(x), ptr(g.contiguous()), z.shape[0], ptr(gz), ptr(gy), ptr(gx),
+                 stream_of(z))
+        return gz, gy, gx
+
+
+class _PoseVec2Mat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vec):
+        ctx.save_for_backward(vec)
+        return _pose_vec2mat_hip(vec)
 
     @staticmethod
-    def backward(ctx, *gouts):
-        ins = [t.detach().requires_grad_(ctx.needs_input_grad[2 + k]) for k, t in enumerate(ctx.saved_tensors)]
-        with torch.enable_grad():
-            outs = ctx.torch_fn(*ins)
-        outs = outs if isinstance(outs, tuple) else (outs,)
-        pairs = [(o, g) for o, g in zip(outs, gouts) if g is not None and o.requires_grad]
-        wanted = [t for t in ins if t.requires_grad]
-        grads = iter(torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True)) if pairs \
-            else iter([None] * len(wanted))
-        return (None, None) + tuple(next(grads) if t.requires_grad else None for t in ins)
+    def backward(ctx, g):
+        vec, = ctx.saved_tensors
+        gvec = torch.empty_like(vec)
+        with torch.cuda.device(vec.device):
+            call("sfm_pose_vec2mat_bwd", ptr(vec), ptr(g.contiguous()), vec.shape[0], ptr(gvec), stream_of(vec))
+        return gvec
 
 
-def _euler2mat_torch(z, y, x):
-    bsz = z.shape[0]
-    z = torch.clamp(z, -math.pi, math.pi).reshape(bsz)
-    y = torch.clamp(y, -math.pi, math.pi).reshape(bsz)
-    x = torch.clamp(x, -math.pi, math.pi).reshape(bsz)
-    zeros, ones = torch.zeros_like(z), torch.ones_like(z)
+class _Pixel2Cam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, is_homogeneous, depth, pixel_coords, intrinsics, translations):
+        ctx.homog = bool(is_homogeneous)
+        ctx.save_for_backward(depth, pixel_coords, intrinsics, *([translations] if translations is not None else []))
+        return _pixel2cam_hip(ctx.homog)(depth, pixel_coords, intrinsics, translations)
 
-    def m3(r0, r1, r2):
-        return torch.stack([torch.stack(r0, 1), torch.stack(r1, 1), torch.stack(r2, 1)], 1)
+    @staticmethod
+    def backward(ctx, g):
+        depth, pix, K = ctx.saved_tensors[:3]
+        trans = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
+        B, H, W = depth.shape
+        need = ctx.needs_input_grad
+        dev = depth.device
+        with torch.cuda.device(dev):
+            g_depth = torch.empty_like(depth) if need[1] else None
+            g_pix = torch.empty_like(pix) if need[2] else None
+            g_K = torch.empty_like(K) if need[3] else None
+            g_t = torch.empty_like(trans) if (trans is not None and need[4]) else None
+            call("sfm_pixel2cam_bwd", ptr(depth), ptr(pix), ptr(K), ptr(trans), ptr(g.contiguous()), B, H, W, int(ctx.homog),
+                 ptr(g_depth), ptr(g_pix), ptr(g_K), ptr(g_t), ptr(_geom_ws(B, H, W, dev)), stream_of(depth))
+        return None, g_depth, g_pix, g_K, g_t
 
-    zmat = m3([torch.cos(z), -torch.sin(z), zeros], [torch.sin(z), torch.cos(z), zeros], [zeros, zeros, ones])
-    ymat = m3([torch.cos(y), zeros, torch.sin(y)], [zeros, ones, zeros], [-torch.sin(y), zeros, torch.cos(y)])
-    xmat = m3([ones, zeros, zeros], [zeros, torch.cos(x), -torch.sin(x)], [zeros, torch.sin(x), torch.cos(x)])
-    return torch.matmul(torch.matmul(xmat, ymat), zmat)[:, None]
+
+class _Cam2Pixel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cam_coords, proj):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(cam_coords, proj)
+        return _cam2pixel_hip(cam_coords, proj)
+
+    @staticmethod
+    def backward(ctx, g_xy, g_z):
+        cam, proj = ctx.saved_tensors
+        B, _, H, W = cam.shape
+        need = ctx.needs_input_grad
+        if (g_xy is None and g_z is None) or not (need[0] or need[1]):
+            return None, None
+        dev = cam.device
+        with torch.cuda.device(dev):
+            g_cam = torch.empty_like(cam) if need[0] else None
+            g_proj = torch.empty_like(proj) if need[1] else None
+            call("sfm_cam2pixel_bwd", ptr(cam), ptr(proj), ptr(g_xy.contiguous() if g_xy is not None else None),
+                 ptr(g_z.contiguous() if g_z is not None else None), B, H, W, ptr(g_cam), ptr(g_proj),
+                 ptr(_geom_ws(B, H, W, dev)), stream_of(cam))
+        return g_cam, g_proj
 
 
 def _euler2mat_hip(z, y, x):
@@ -398,15 +442,7 @@ def euler2mat(z, y, x):
     if not (z.shape == y.shape == x.shape):
         raise ValueError("z, y, x must have the same shape [B, 1]")
     _same_device(z, y, x)
-    return _HipForward.apply(_euler2mat_hip, _euler2mat_torch, z, y, x)
-
-
-def _pose_vec2mat_torch(vec):
-    bsz = vec.shape[0]
-    rot = _euler2mat_torch(vec[:, 5:6], vec[:, 4:5], vec[:, 3:4]).squeeze(1)
-    top = torch.cat([rot, vec[:, 0:3, None]], dim=2)
-    filler = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=vec.dtype, device=vec.device).reshape(1, 1, 4).repeat(bsz, 1, 1)
-    return torch.cat([top, filler], dim=1)
+    return _Euler2Mat.apply(z, y, x)
 
 
 def _pose_vec2mat_hip(vec):
@@ -419,7 +455,7 @@ def _pose_vec2mat_hip(vec):
 def pose_vec2mat(vec):
     """utils.py:77-96: [B,6] = (tx,ty,tz,rx,ry,rz) -> [B,4,4] (``sfm_pose_vec2mat``)."""
     vec = _check(vec, "vec", 2, 6)
-    return _HipForward.apply(_pose_vec2mat_hip, _pose_vec2mat_torch, vec)
+    return _PoseVec2Mat.apply(vec)
 
 
 def meshgrid(batch, height, width, is_homogeneous=True, device=None):
@@ -435,18 +471,6 @@ def meshgrid(batch, height, width, is_homogeneous=True, device=None):
         call("sfm_meshgrid", int(batch), int(height), int(width), int(bool(is_homogeneous)), ptr(out),
              stream_of(out))
     return out
-
-
-def _pixel2cam_torch(is_homogeneous):
-    def fn(depth, pixel_coords, intrinsics, translations=None):
-        batch, height, width = depth.shape
-        cam = torch.matmul(torch.linalg.inv(intrinsics), pixel_coords.reshape(batch, 3, -1)) * depth.reshape(batch, 1, -1)
-        if translations is not None:
-            cam = cam + translations.permute(0, 3, 1, 2).reshape(batch, 3, -1) * cam
-        if is_homogeneous:
-            cam = torch.cat([cam, torch.ones(batch, 1, height * width, dtype=cam.dtype, device=cam.device)], dim=1)
-        return cam.reshape(batch, -1, height, width)
-    return fn
 
 
 def _pixel2cam_hip(is_homogeneous):
@@ -477,16 +501,7 @@ def pixel2cam(depth, pixel_coords, intrinsics, is_homogeneous=True, add_trans=Fa
             raise ValueError(f"translations must be {(batch, height, width, 3)}, got {tuple(trans.shape)}")
         args.append(trans)
     _same_device(*args)
-    return _HipForward.apply(_pixel2cam_hip(bool(is_homogeneous)), _pixel2cam_torch(bool(is_homogeneous)), *args)
-
-
-def _cam2pixel_torch(cam_coords, proj):
-    batch, _, height, width = cam_coords.shape
-    un = torch.matmul(proj, cam_coords.reshape(batch, 4, -1))
-    x_n = un[:, 0:1] / (un[:, 2:3] + 1e-10)
-    y_n = un[:, 1:2] / (un[:, 2:3] + 1e-10)
-    pix = torch.cat([x_n, y_n], dim=1).reshape(batch, 2, height, width)
-    return pix.permute(0, 2, 3, 1), un[:, 2:3].reshape(batch, 1, height, width).permute(0, 2, 3, 1)
+    return _Pixel2Cam.apply(bool(is_homogeneous), *args, *([None] if len(args) == 3 else []))
 
 
 def _cam2pixel_hip(cam_coords, proj):
@@ -505,4 +520,4 @@ def cam2pixel(cam_coords, proj) -> Tuple[Tensor, Tensor]:
     if cam_coords.shape[1] != 4 or tuple(proj.shape) != (cam_coords.shape[0], 4, 4):
         raise ValueError("cam_coords must be [batch, 4, height, width] and proj [batch, 4, 4]")
     _same_device(cam_coords, proj)
-    return _HipForward.apply(_cam2pixel_hip, _cam2pixel_torch, cam_coords, proj)
+    return _Cam2Pixel.apply(cam_coords, proj)

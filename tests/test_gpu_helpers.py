@@ -1,6 +1,6 @@
 """The geometry helpers utils.py exports (euler2mat, pose_vec2mat, meshgrid, pixel2cam, cam2pixel: utils.py:27-170) as
 stand-alone HIP operators: forward BIT-EXACT against the oracle's canonical fp32 op order (these feed integer pixel
-indices), gradients (torch autograd of the same formula on the device) against autograd of the oracle at 1e-4, and the
+indices), gradients (hand-written adjoints, csrc/geom.hip) against autograd of the oracle at 1e-4, and the
 reference's own composition utils.py:185-202 rebuilt from the pieces against the fused sfm_project_coords."""
 import math
 
@@ -87,6 +87,50 @@ def test_helper_gradients_match_the_oracle(dev):
     got = run(sfm_amd, lambda v: v.to(dev))
     for a, b, name in zip(got, ref, ("d_vec", "d_depth", "d_trans")):
         assert rel_err(a, b) <= TOL_GRAD, name
+
+
+@pytest.mark.parametrize("B,H,W,add_trans,homog", [(2, 9, 11, True, True), (1, 17, 40, False, True), (3, 5, 7, True, True)])
+def test_every_helper_adjoint_is_hand_written_and_matches_the_oracle(dev, B, H, W, add_trans, homog):
+    """csrc/geom.hip's adjoints one by one against autograd of the oracle: euler2mat (angles beyond +-pi included: the clip
+    stops the gradient), pose_vec2mat, pixel2cam with respect to depth, pixel grid, INTRINSICS (through the matrix
+    inverse) and translations, cam2pixel with respect to the camera points and the projection matrix - with both
+    outputs used, and with only one of them"""
+    g = torch.Generator().manual_seed(11)
+    inp = synth.make_inputs(B, H, W, S=1, N=2, seed=79, pose_scale=0.05)
+    ang = [torch.randn(B, 1, generator=g) * 2.5 for _ in range(3)]   # some beyond pi
+    wR = torch.randn(B, 1, 3, 3, generator=g)
+    wT = torch.randn(B, 4, 4, generator=g)
+
+    def leaves(to):
+        return dict(z=to(ang[0]).requires_grad_(True), y=to(ang[1]).requires_grad_(True), x=to(ang[2]).requires_grad_(True),
+                    vec=to(inp["pose"][:, 1].contiguous()).requires_grad_(True),
+                    depth=to(inp["depth"][0].squeeze(3).contiguous()).requires_grad_(True),
+                    K=to(inp["K"].clone()).requires_grad_(True),
+                    t=to(inp["trans"][0][..., 3:6].contiguous()).requires_grad_(True))
+
+    for use in ("both", "coords", "z"):
+        res = []
+        for mod, to in ((R, lambda v: v.detach().clone()), (sfm_amd, lambda v: v.detach().to(dev))):
+            L = leaves(to)
+            pix = (mod.meshgrid(B, H, W) if mod is R else mod.meshgrid(B, H, W, device=dev)).requires_grad_(True)
+            rot = mod.euler2mat(L["z"], L["y"], L["x"])
+            T = mod.pose_vec2mat(L["vec"])
+            cam = mod.pixel2cam(L["depth"], pix, L["K"], homog, add_trans, L["t"] if add_trans else None)
+            proj = T * to(wT) + to(wT)      # a dense [B,4,4] that depends on vec
+            xy, zz = mod.cam2pixel(cam, proj)
+            loss = (rot * to(wR)).sum()
+            if use in ("both", "coords"):
+                loss = loss + (xy * xy).sum() * 1e-3
+            if use in ("both", "z"):
+                loss = loss + (zz * zz).sum()
+            loss.backward()
+            out = {k: v.grad for k, v in L.items() if (k != "t" or add_trans)}
+            out["pix"] = pix.grad
+            res.append(out)
+        ref, got = res
+        for k in ref:
+            assert got[k] is not None, (k, use)
+            assert rel_err(got[k], ref[k]) <= TOL_GRAD, (k, use, rel_err(got[k], ref[k]))
 
 
 def test_helpers_reject_cpu_tensors():
