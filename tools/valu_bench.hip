@@ -55,6 +55,33 @@ DPP_KERNEL(k_add_row, "v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask
 DPP_KERNEL(k_add_wave, "v_add_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
 DPP_KERNEL(k_mov_wave, "v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1 ; %2")
 DPP_KERNEL(k_fmac_plain, "v_fmac_f32 %0, %1, %2")
+__global__ __launch_bounds__(256) void k_cvt64(float* out, float a, float b) {
+  float x[8]; double y[8];
+  for (int i = 0; i < 8; ++i) { x[i] = threadIdx.x + i; y[i] = 0; }
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(y[i]) : "v"(x[i]));
+  double s = 0; for (int i = 0; i < 8; ++i) s += y[i];
+  out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+}
+__global__ __launch_bounds__(256) void k_dmul(float* out, float a, float b) {
+  double y[8], da = a, db = b;
+  for (int i = 0; i < 8; ++i) y[i] = threadIdx.x + i;
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(y[i]) : "v"(da), "v"(db));
+  double s = 0; for (int i = 0; i < 8; ++i) s += y[i];
+  out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+}
+__global__ __launch_bounds__(256) void k_dfma(float* out, float a, float b) {
+  double y[8], da = a, db = b;
+  for (int i = 0; i < 8; ++i) y[i] = threadIdx.x + i;
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(y[i]) : "v"(da), "v"(db));
+  double s = 0; for (int i = 0; i < 8; ++i) s += y[i];
+  out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+}
 template <typename K> void run(const char* name, K k, int blocks, float* out) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
@@ -71,6 +98,7 @@ int main() {
   for (int blocks : {256, 512, 2048}) {   // 1, 2, 8 waves per SIMD
     run("v_fma", k_fma, blocks, out); run("v_pk_fma", k_pkfma, blocks, out); run("add_dpp", k_dpp, blocks, out); run("v_rcp", k_rcp, blocks, out);
     run("fmac", k_fmac_plain, blocks, out); run("fmac_wave", k_fmac_wave, blocks, out); run("fmac_row", k_fmac_row, blocks, out);
+    run("cvt_f64_f32", k_cvt64, blocks, out); run("mul_f64", k_dmul, blocks, out); run("fma_f64", k_dfma, blocks, out);
     run("add_row", k_add_row, blocks, out); run("add_wave", k_add_wave, blocks, out); run("mov_wave", k_mov_wave, blocks, out);
   }
   return 0;
